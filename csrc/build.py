@@ -1,0 +1,120 @@
+"""Build the native libraries in-tree for gfx950.
+
+Produces, under ``pytorch_distributed_training_amd/_lib/``:
+
+* ``libpdt_core.so``    - reducer core + loopback fabric (plain C++, no GPU runtime)
+* ``libpdt_rccl.so``    - RCCL transport on a dedicated HIP stream (links amdhip64 + rccl)
+* ``libpdt_kernels.so`` - every HIP kernel in ``csrc/kernels`` (``--offload-arch=gfx950``)
+
+The libraries expose a C ABI and are loaded with ctypes, so the build needs no PyTorch
+headers and a cold build takes well under a minute.  hipcc cross-compiles without a GPU.
+Objects are rebuilt only when a source or header is newer.
+"""
+
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+from typing import List
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "csrc"
+OUT = ROOT / "pytorch_distributed_training_amd" / "_lib"
+OBJ = ROOT / "build" / "obj"
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), str(ROCM / "bin" / "hipcc"), shutil.which("hipcc")):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found; set HIPCC or ROCM_PATH")
+
+
+def _newer(target: Path, deps: List[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _run(cmd: List[str]) -> None:
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + "\n")
+        raise RuntimeError(f"build step failed: {cmd[0]} ... {cmd[-1]}")
+    if res.stdout.strip() and os.environ.get("PDT_BUILD_VERBOSE"):
+        sys.stderr.write(res.stdout)
+
+
+def build_core(force: bool = False) -> Path:
+    srcs = [CSRC / "reducer" / "reducer_core.cpp", CSRC / "reducer" / "loopback.cpp"]
+    deps = srcs + [CSRC / "reducer" / "reducer_core.h"]
+    out = OUT / "libpdt_core.so"
+    if force or _newer(out, deps):
+        cxx = os.environ.get("CXX", "g++")
+        _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-o", str(out)] + [str(s) for s in srcs])
+    return out
+
+
+def build_rccl(force: bool = False) -> Path:
+    src = CSRC / "reducer" / "reducer_rccl.cpp"
+    deps = [src, CSRC / "reducer" / "reducer_core.h"]
+    out = OUT / "libpdt_rccl.so"
+    if force or _newer(out, deps):
+        _run(
+            [
+                _hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", f"--offload-arch={ARCH}",
+                "-D__HIP_PLATFORM_AMD__", f"-I{ROCM / 'include'}", "-Wall", "-o", str(out), str(src),
+                f"-L{ROCM / 'lib'}", "-lamdhip64", "-lrccl",
+            ]
+        )
+    return out
+
+
+def _compile_kernel(src: Path, headers: List[Path], force: bool) -> Path:
+    obj = OBJ / (src.stem + ".o")
+    if force or _newer(obj, [src] + headers):
+        _run(
+            [
+                _hipcc(), "-O3", "-std=c++17", "-fPIC", "-c", f"--offload-arch={ARCH}", "-ffast-math",
+                "-Wall", "-Wno-unused-function", f"-I{CSRC / 'kernels'}", "-o", str(obj), str(src),
+            ]
+        )
+    return obj
+
+
+def build_kernels(force: bool = False, jobs: int = 0) -> Path:
+    kdir = CSRC / "kernels"
+    srcs = sorted(kdir.glob("*.hip"))
+    headers = sorted(kdir.glob("*.h")) + sorted(kdir.glob("*.hpp"))
+    out = OUT / "libpdt_kernels.so"
+    if not srcs:
+        return out
+    jobs = jobs or min(8, int(os.environ.get("MAX_JOBS", "8")), len(srcs))
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile_kernel(s, headers, force), srcs))
+    if force or _newer(out, objs):
+        _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(out)] + [str(o) for o in objs]
+             + [f"-L{ROCM / 'lib'}", "-lamdhip64"])
+    return out
+
+
+def build_all(force: bool = False) -> List[Path]:
+    OUT.mkdir(parents=True, exist_ok=True)
+    OBJ.mkdir(parents=True, exist_ok=True)
+    return [build_core(force), build_rccl(force), build_kernels(force)]
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--force", action="store_true")
+    args = ap.parse_args()
+    for p in build_all(args.force):
+        print(p)

@@ -1,0 +1,113 @@
+"""Fused operators.
+
+Every op has exactly one GPU implementation - a hand-written gfx950 HIP kernel wrapped in
+an ``autograd.Function`` (``ops.hip``) - and a plain PyTorch definition (``ops.reference``)
+that states its semantics, runs for CPU tensors and is the oracle in numerics tests.
+Dispatch is by device only: a GPU tensor never takes the PyTorch composition, and a missing
+kernel library is an error, not a fallback.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import reference as _ref
+
+
+def _hip():
+    from . import hip  # imported lazily: loading it maps the kernel library
+
+    return hip
+
+
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0):
+    """Convolution without bias.  Returns ``(y, stats)`` where ``stats`` carries the per-channel
+    batch statistics of ``y`` gathered in the kernel epilogue (``None`` on CPU)."""
+    if x.is_cuda:
+        return _hip().conv2d_stats(x, weight, stride, padding)
+    return _ref.conv2d_stats(x, weight, stride, padding)
+
+
+def bn_act(y, stats, bn, relu: bool = True):
+    """BatchNorm (+ReLU) of a raw convolution output."""
+    if y.is_cuda:
+        return _hip().bn_act(y, stats, bn, relu)
+    return _ref.bn_act(y, stats, bn, relu)
+
+
+def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
+    """conv(relu(bn(y_prev))) with the normalisation applied on the way into the convolution."""
+    if y_prev.is_cuda:
+        return _hip().bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride, padding)
+    return _ref.bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride, padding)
+
+
+def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
+    """relu(bn(y) + identity), or relu(bn(y) + id_bn(identity)) for a projected shortcut."""
+    if y.is_cuda:
+        return _hip().bn_add_relu(y, stats, bn, identity, id_stats, id_bn)
+    return _ref.bn_add_relu(y, stats, bn, identity, id_stats, id_bn)
+
+
+def bn_relu_maxpool(y, stats, bn):
+    """Stem tail: maxpool3x3/2(relu(bn(y)))."""
+    if y.is_cuda:
+        return _hip().bn_relu_maxpool(y, stats, bn)
+    return _ref.bn_relu_maxpool(y, stats, bn)
+
+
+def global_avgpool(a):
+    if a.is_cuda:
+        return _hip().global_avgpool(a)
+    return _ref.global_avgpool(a)
+
+
+def linear(x, weight, bias=None, activation: Optional[str] = None):
+    if x.is_cuda:
+        return _hip().linear(x, weight, bias, activation)
+    return _ref.linear(x, weight, bias, activation)
+
+
+def softmax_cross_entropy(logits, labels):
+    if logits.is_cuda:
+        return _hip().softmax_cross_entropy(logits, labels)
+    return _ref.softmax_cross_entropy(logits, labels)
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    if x.is_cuda:
+        return _hip().layer_norm(x, weight, bias, eps)
+    return _ref.layer_norm(x, weight, bias, eps)
+
+
+def gelu(x):
+    if x.is_cuda:
+        return _hip().gelu(x)
+    return _ref.gelu(x)
+
+
+def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
+    if q.is_cuda:
+        return _hip().attention(q, k, v, causal, scale)
+    return _ref.attention(q, k, v, causal, scale)
+
+
+def embedding(ids, weight):
+    if weight.is_cuda:
+        return _hip().embedding(ids, weight)
+    return _ref.embedding(ids, weight)
+
+
+def add_bias_residual(x, bias, residual):
+    if x.is_cuda:
+        return _hip().add_bias_residual(x, bias, residual)
+    return _ref.add_bias_residual(x, bias, residual)
+
+
+def to_device_layout(x, dtype=torch.bfloat16):
+    """NCHW float batch -> compute dtype in the layout the GPU kernels read (NHWC / channels_last)."""
+    if x.is_cuda:
+        return _hip().to_device_layout(x, dtype)
+    return x.to(dtype)

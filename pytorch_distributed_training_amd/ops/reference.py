@@ -1,0 +1,109 @@
+"""Plain PyTorch implementations of every fused op.
+
+They define the semantics: the HIP kernels are tested against them, and they are what runs
+for CPU tensors (the gloo plumbing configuration and unit tests).  They are ordinary
+differentiable compositions, so autograd provides their backward passes.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def batch_norm(y: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
+    """Training-mode batch statistics (and running-stat update) or eval-mode running statistics."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    use_batch = bn.training or not bn.track_running_stats
+    return F.batch_norm(
+        y,
+        bn.running_mean if bn.track_running_stats else None,
+        bn.running_var if bn.track_running_stats else None,
+        bn.weight,
+        bn.bias,
+        use_batch,
+        bn.momentum if bn.momentum is not None else 0.1,
+        bn.eps,
+    )
+
+
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0):
+    return F.conv2d(x, weight, None, stride, padding), None
+
+
+def bn_act(y, stats, bn, relu: bool = True):
+    z = batch_norm(y, bn)
+    return F.relu(z) if relu else z
+
+
+def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
+    return F.conv2d(F.relu(batch_norm(y_prev, bn)), weight, None, stride, padding), None
+
+
+def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
+    z = batch_norm(y, bn)
+    if id_bn is not None:
+        identity = batch_norm(identity, id_bn)
+    return F.relu(z + identity)
+
+
+def bn_relu_maxpool(y, stats, bn):
+    return F.max_pool2d(F.relu(batch_norm(y, bn)), kernel_size=3, stride=2, padding=1)
+
+
+def global_avgpool(a: torch.Tensor) -> torch.Tensor:
+    return a.mean(dim=(2, 3))
+
+
+def linear(x, weight, bias=None, activation: Optional[str] = None):
+    out = F.linear(x, weight, bias)
+    if activation == "gelu":
+        out = F.gelu(out, approximate="tanh")
+    elif activation == "relu":
+        out = F.relu(out)
+    return out
+
+
+def softmax_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """Mean softmax cross-entropy over all rows (role of ``nn.CrossEntropyLoss()`` at
+    /root/reference/src/main.py:62,76)."""
+    return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), labels.reshape(-1))
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def gelu(x):
+    return F.gelu(x, approximate="tanh")
+
+
+def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
+    """softmax(q k^T * scale [+ causal mask]) v for [B, H, S, D] tensors."""
+    d = q.shape[-1]
+    scale = scale if scale is not None else 1.0 / math.sqrt(d)
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
+    if causal:
+        sq, sk = s.shape[-2], s.shape[-1]
+        mask = torch.ones(sq, sk, dtype=torch.bool, device=s.device).tril(sk - sq)
+        s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.matmul(p, v.float()).to(q.dtype)
+
+
+def embedding(ids, weight):
+    return F.embedding(ids, weight)
+
+
+def add_bias_residual(x, bias, residual):
+    out = x
+    if bias is not None:
+        out = out + bias
+    if residual is not None:
+        out = out + residual
+    return out

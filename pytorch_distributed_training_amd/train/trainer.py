@@ -1,0 +1,379 @@
+"""Training / evaluation loop.
+
+Covers the reference's loop (/root/reference/src/main.py:61-84: DataLoader, CrossEntropy,
+Adam, one pass of ``zero_grad -> forward -> loss -> backward -> step`` under a tqdm bar,
+elapsed-time report) and the capabilities the reference lacks: sharded sampling, epochs,
+evaluation, throughput metering, rank-0 checkpoint/resume, gradient accumulation, failure
+detection.  The five printed contract lines are preserved verbatim.
+"""
+
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+from tqdm import tqdm
+
+from .. import ops
+from ..data import (
+    DevicePrefetcher,
+    DeviceSyntheticLoader,
+    build_dataset,
+    build_loader,
+    synthetic_image_batches,
+    synthetic_token_batches,
+)
+from ..models import MODELS, build_model
+from ..optim import build_optimizer
+from ..parallel import DistEnv, barrier, init_distributed, shutdown, wrap_data_parallel
+from ..utils.logging import get_logger, rank_zero_print
+from ..utils.meter import AverageMeter, ThroughputMeter
+from ..utils.timers import ChromeTrace, StepTimer
+from ..utils.watchdog import GracefulStop, StepWatchdog, maybe_inject_fault
+from . import checkpoint as ckpt
+
+log = get_logger("pdt.train")
+
+
+@dataclass
+class TrainConfig:
+    # --- the reference's seven flags (main.py:19-25), same defaults
+    data_dir: str = "~/Downloads/data"
+    distributed: bool = False
+    use_cpu: bool = False
+    batch_size: int = 32  # per process
+    num_workers: int = 2
+    learning_rate: float = 0.1
+    weight_decay: float = 0.001
+    # --- additive options
+    model: str = "resnet18"
+    dataset: str = "auto"  # auto | cifar10 | synthetic
+    num_classes: int = 0  # 0 => dataset / model default
+    image_size: int = 0
+    seq_len: int = 1024
+    epochs: int = 1
+    steps: int = 0  # >0: stop after this many optimisation steps in total
+    warmup_steps: int = 0  # steps excluded from the throughput window
+    dtype: str = "auto"  # auto: bf16 on GPU, fp32 on CPU
+    optimizer: str = "adam"
+    momentum: float = 0.9
+    grad_accum: int = 1
+    shuffle: bool = False
+    drop_last: bool = False
+    train_split: bool = False  # reference trains on the CIFAR-10 *test* split (main.py:47)
+    evaluate: bool = False
+    checkpoint_path: str = ""
+    resume: str = ""
+    save_every: int = 0  # steps; 0 => only at the end
+    bucket_mb: float = 25.0
+    first_bucket_mb: float = 1.0
+    sync_buffers: bool = True
+    native_rccl: bool = True
+    device_data: bool = False  # keep synthetic batches resident on the device
+    dataset_length: int = 0
+    seed: int = 0
+    log_every: int = 0
+    progress: bool = True
+    watchdog_s: float = 0.0
+    dist_timeout_s: float = 600.0
+    profile: str = ""  # path of a chrome trace with per-phase host spans
+    check_finite: bool = False
+
+
+@dataclass
+class TrainResult:
+    steps: int = 0
+    epochs: int = 0
+    elapsed_s: float = 0.0
+    samples_per_sec: float = 0.0
+    ms_per_step: float = 0.0
+    final_loss: float = float("nan")
+    eval_accuracy: Optional[float] = None
+    eval_loss: Optional[float] = None
+    losses: list = field(default_factory=list)
+    interrupted: bool = False
+
+
+def resolve_dtype(cfg: TrainConfig, device: torch.device) -> torch.dtype:
+    if cfg.dtype == "auto":
+        return torch.bfloat16 if device.type == "cuda" else torch.float32
+    return {"fp32": torch.float32, "bf16": torch.bfloat16}[cfg.dtype]
+
+
+def prepare_image_batch(x: torch.Tensor, device: torch.device, dtype: torch.dtype) -> torch.Tensor:
+    """Device placement, compute dtype and (on GPU) NHWC layout for an NCHW float batch."""
+    x = x.to(device=device, non_blocking=True)
+    if device.type == "cuda":
+        return ops.to_device_layout(x, dtype)
+    return x.to(dtype)
+
+
+class Trainer:
+    def __init__(self, cfg: TrainConfig, env: Optional[DistEnv] = None):
+        self.cfg = cfg
+        self._owns_env = env is None
+        self.env = env if env is not None else init_distributed(cfg.distributed, cfg.use_cpu, cfg.dist_timeout_s)
+        if self.env.distributed:
+            # contract line 1 (main.py:42)
+            print(f"Process group initialized - WORLD_SIZE: {self.env.world_size}, RANK: {self.env.rank}", flush=True)
+        torch.manual_seed(cfg.seed)
+        self.device = self.env.device
+        self.dtype = resolve_dtype(cfg, self.device)
+        spec = MODELS[cfg.model]
+        self.kind = spec.kind
+        self.image_size = cfg.image_size or spec.default_image_size
+        self.num_classes = cfg.num_classes or spec.default_num_classes
+
+        lm_model = build_model(cfg.model) if self.kind == "lm" else None
+        vocab = lm_model.vocab_size if lm_model is not None else 0
+        if lm_model is not None and cfg.seq_len > lm_model.n_ctx:
+            raise ValueError(f"--seq-len {cfg.seq_len} exceeds the model context {lm_model.n_ctx}")
+        self.dataset, self.data_desc = build_dataset(
+            cfg.dataset, cfg.data_dir, self.kind, self.image_size, self.num_classes,
+            cfg.dataset_length or None, cfg.seq_len, vocab or 50257, train=cfg.train_split, seed=cfg.seed,
+        )
+        if self.kind == "image" and hasattr(self.dataset, "classes") and not cfg.num_classes:
+            self.num_classes = len(self.dataset.classes)  # main.py:49
+
+        model = lm_model if lm_model is not None else build_model(cfg.model, self.num_classes, self.image_size)
+        model = model.to(self.device)
+        if self.device.type == "cuda":
+            model = model.to(memory_format=torch.channels_last)
+        self.raw_model = model
+        if self.env.distributed:
+            model = wrap_data_parallel(
+                model, self.env, cfg.bucket_mb, cfg.first_bucket_mb, cfg.sync_buffers, cfg.native_rccl
+            )
+        self.model = model
+        # contract line 2 (main.py:59)
+        print(f"Device - {self.env.device_label}", flush=True)
+
+        self.optimizer = build_optimizer(
+            [p for p in self.raw_model.parameters() if p.requires_grad],
+            cfg.optimizer, cfg.learning_rate, cfg.weight_decay, cfg.momentum,
+        )
+        self.start_epoch = 0
+        self.global_step = 0
+        if cfg.resume:
+            info = ckpt.load_checkpoint(cfg.resume, self.model, self.optimizer)
+            self.start_epoch, self.global_step = info["epoch"], info["step"]
+            rank_zero_print(f"Resumed from {cfg.resume} at epoch {self.start_epoch}, step {self.global_step}")
+        self.timer = StepTimer(self.device, enabled=bool(cfg.profile))
+        self.trace = ChromeTrace(self.env.rank) if cfg.profile else None
+        self.stopper = GracefulStop()
+
+    # ------------------------------------------------------------------ data
+    def _make_loader(self):
+        cfg = self.cfg
+        if cfg.device_data:
+            steps = cfg.steps or math.ceil(len(self.dataset) / (cfg.batch_size * self.env.world_size))
+            if self.kind == "lm":
+                make = synthetic_token_batches(cfg.batch_size, cfg.seq_len, self.raw_model.vocab_size, self.device,
+                                               cfg.seed + self.env.rank)
+            else:
+                base = synthetic_image_batches(cfg.batch_size, self.image_size, self.num_classes, "cpu",
+                                               seed=cfg.seed + self.env.rank)
+
+                def make(i):
+                    x, y = base(i)
+                    return prepare_image_batch(x, self.device, self.dtype), y.to(self.device)
+
+            return DeviceSyntheticLoader(make, steps), None
+        loader, sampler = build_loader(
+            self.dataset, cfg.batch_size, cfg.num_workers, self.env.rank, self.env.world_size,
+            shuffle=cfg.shuffle, drop_last=cfg.drop_last, pin_memory=self.device.type == "cuda", seed=cfg.seed,
+        )
+        if self.device.type == "cuda":
+            loader = DevicePrefetcher(loader, self.device)
+        return loader, sampler
+
+    # ------------------------------------------------------------------ one step
+    def _forward_loss(self, batch) -> torch.Tensor:
+        if self.kind == "lm":
+            ids, targets = batch
+            return self.model(ids.to(self.device), targets.to(self.device))
+        imgs, lbls = batch
+        if imgs.device != self.device or imgs.dtype != self.dtype:
+            imgs = prepare_image_batch(imgs, self.device, self.dtype)
+        preds = self.model(imgs)
+        return ops.softmax_cross_entropy(preds, lbls.to(self.device))
+
+    def _zero_grad(self) -> None:
+        if hasattr(self.model, "reducer"):
+            self.model.reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=False)
+
+    def train_step(self, batch, accumulate: bool = False) -> torch.Tensor:
+        """forward + backward (+ optimizer step unless ``accumulate``); returns the detached loss."""
+        cfg = self.cfg
+        span = self.trace.span if self.trace else None
+        sync_ctx = self.model.no_sync() if (accumulate and hasattr(self.model, "no_sync")) else _null()
+        with sync_ctx:
+            with self.timer.phase("forward"), (span("forward") if span else _null()):
+                loss = self._forward_loss(batch)
+                if cfg.grad_accum > 1:
+                    loss = loss / cfg.grad_accum
+            with self.timer.phase("backward"), (span("backward") if span else _null()):
+                loss.backward()
+        if not accumulate:
+            with self.timer.phase("optimizer"), (span("optimizer") if span else _null()):
+                self.optimizer.step()
+                self._zero_grad()
+        return loss.detach()
+
+    # ------------------------------------------------------------------ loops
+    def fit(self) -> TrainResult:
+        cfg, env = self.cfg, self.env
+        res = TrainResult()
+        loader, sampler = self._make_loader()
+        sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else None
+        meter = ThroughputMeter(env.world_size, cfg.warmup_steps, sync)
+        loss_meter = AverageMeter()
+        self.model.train()
+        self._zero_grad()
+        self.stopper.install()
+        dog = StepWatchdog(cfg.watchdog_s, env.rank).start()
+
+        t0 = time.perf_counter()
+        print("Training starting...", flush=True)  # contract line 3 (main.py:66)
+        meter.start()
+        done = False
+        last_loss = None
+        steps_this_run = 0
+        epoch = self.start_epoch
+        try:
+            for epoch in range(self.start_epoch, cfg.epochs):
+                if sampler is not None:
+                    sampler.set_epoch(epoch)
+                bar = tqdm(loader, disable=not (cfg.progress and env.is_main), desc=f"epoch {epoch}" if cfg.epochs > 1 else None)
+                micro = 0
+                for batch in bar:
+                    micro += 1
+                    accumulate = (micro % cfg.grad_accum) != 0
+                    last_loss = self.train_step(batch, accumulate)
+                    if accumulate:
+                        continue
+                    self.global_step += 1
+                    steps_this_run += 1
+                    meter.step(_batch_len(batch) * cfg.grad_accum)
+                    dog.beat(self.global_step)
+                    maybe_inject_fault(env.rank, self.global_step)
+                    if cfg.log_every and self.global_step % cfg.log_every == 0:
+                        lv = float(last_loss) * cfg.grad_accum
+                        loss_meter.update(lv)
+                        res.losses.append(lv)
+                        if cfg.check_finite and not math.isfinite(lv):
+                            raise FloatingPointError(f"non-finite loss {lv} at step {self.global_step}")
+                        if env.is_main:
+                            bar.set_postfix(loss=f"{lv:.4f}", refresh=False)
+                    if cfg.save_every and cfg.checkpoint_path and self.global_step % cfg.save_every == 0:
+                        self.save(epoch)
+                    if self.stopper.requested or (cfg.steps and steps_this_run >= cfg.steps):
+                        done = True
+                        break
+                res.epochs = epoch + 1 - self.start_epoch
+                if done:
+                    break
+        finally:
+            dog.stop()
+            self.stopper.uninstall()
+        meter.stop()
+        t1 = time.perf_counter()
+        print("Training complete", flush=True)  # contract line 4 (main.py:82)
+        print(f"Elapsed time: {t1 - t0}", flush=True)  # contract line 5 (main.py:84)
+
+        res.steps = steps_this_run
+        res.elapsed_s = t1 - t0
+        res.samples_per_sec = meter.samples_per_sec
+        res.ms_per_step = meter.ms_per_step
+        res.interrupted = self.stopper.requested
+        if last_loss is not None:
+            res.final_loss = float(last_loss) * cfg.grad_accum
+        unit = "tokens/sec" if self.kind == "lm" else "images/sec"
+        scale = cfg.seq_len if self.kind == "lm" else 1
+        if meter.timed_steps:
+            rank_zero_print(
+                f"Throughput: {meter.samples_per_sec * scale:.1f} {unit} over {meter.timed_steps} steps "
+                f"({meter.ms_per_step:.2f} ms/step, world size {env.world_size}, {self.data_desc})"
+            )
+        if cfg.evaluate:
+            res.eval_loss, res.eval_accuracy = self.evaluate()
+            if res.eval_accuracy is not None:
+                rank_zero_print(f"Eval: loss {res.eval_loss:.4f}, accuracy {100 * res.eval_accuracy:.2f}%")
+            else:
+                rank_zero_print(f"Eval: loss {res.eval_loss:.4f}")
+        if cfg.checkpoint_path:
+            self.save(epoch + (0 if done else 1))
+            rank_zero_print(f"Checkpoint written to {cfg.checkpoint_path}")
+        if cfg.profile:
+            if self.trace and env.is_main:
+                self.trace.dump(cfg.profile)
+            rank_zero_print(self.timer.format())
+        return res
+
+    @torch.no_grad()
+    def evaluate(self):
+        """Mean loss and top-1 accuracy over the (sharded) dataset, reduced across ranks."""
+        env = self.env
+        was_training = self.model.training
+        self.model.eval()
+        loader, _ = build_loader(self.dataset, self.cfg.batch_size, 0, env.rank, env.world_size, shuffle=False)
+        tot = torch.zeros(3, dtype=torch.float64, device=self.device)  # loss_sum, correct, count
+        for batch in loader:
+            if self.kind == "lm":
+                ids, targets = batch
+                loss = self.raw_model(ids.to(self.device), targets.to(self.device))
+                n = ids.shape[0]
+                tot[0] += loss.double() * n
+                tot[2] += n
+            else:
+                imgs, lbls = batch
+                lbls = lbls.to(self.device)
+                preds = self.raw_model(prepare_image_batch(imgs, self.device, self.dtype))
+                loss = ops.softmax_cross_entropy(preds, lbls)
+                n = lbls.shape[0]
+                tot[0] += loss.double() * n
+                tot[1] += (preds.argmax(dim=1) == lbls).sum().double()
+                tot[2] += n
+        if env.distributed:
+            t = tot.to(torch.float32) if env.backend == "gloo" else tot
+            torch.distributed.all_reduce(t)
+            tot = t.to(torch.float64)
+        self.model.train(was_training)
+        count = max(float(tot[2]), 1.0)
+        acc = float(tot[1]) / count if self.kind == "image" else None
+        return float(tot[0]) / count, acc
+
+    def save(self, epoch: int) -> None:
+        ckpt.save_checkpoint(self.cfg.checkpoint_path, self.model, self.env, self.optimizer, epoch, self.global_step)
+
+    def close(self) -> None:
+        if hasattr(self.model, "reducer"):
+            self.model.reducer.close()
+        if self._owns_env:
+            shutdown(self.env)
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _batch_len(batch) -> int:
+    return int(batch[0].shape[0])
+
+
+def run_training(cfg: TrainConfig) -> TrainResult:
+    trainer = Trainer(cfg)
+    try:
+        return trainer.fit()
+    finally:
+        trainer.close()

@@ -1,0 +1,103 @@
+"""Plumbing configuration: ResNet-18 on CIFAR-shaped synthetic data, gloo, world_size=2, CPU."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+
+
+def _small_cnn(seed):
+    torch.manual_seed(seed)
+    return nn.Sequential(
+        nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1),
+        nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 10),
+    )
+
+
+def _worker_parity(rank, world, port, tmp):
+    _init(rank, world, port)
+    from pytorch_distributed_training_amd.parallel import init_distributed, shutdown, wrap_data_parallel
+    from torch.nn.parallel import DistributedDataParallel
+
+    env = init_distributed(True, use_cpu=True, timeout_s=120)
+    assert env.backend == "gloo" and env.world_size == world and env.rank == rank
+    ours = wrap_data_parallel(_small_cnn(seed=rank), env, bucket_mb=0.002, first_bucket_mb=0.0005)
+    stock = DistributedDataParallel(_small_cnn(seed=0))
+    # init broadcast made every rank equal to rank 0
+    for a, b in zip(ours.module.parameters(), stock.module.parameters()):
+        assert torch.equal(a, b)
+    opt_a = torch.optim.SGD(ours.module.parameters(), lr=0.05)
+    opt_b = torch.optim.SGD(stock.parameters(), lr=0.05)
+    g = torch.Generator().manual_seed(100 + rank)
+    for step in range(4):
+        x = torch.randn(4, 3, 8, 8, generator=g)
+        y = torch.randint(0, 10, (4,), generator=g)
+        ours.zero_grad()
+        opt_b.zero_grad()
+        nn.functional.cross_entropy(ours(x), y).backward()
+        nn.functional.cross_entropy(stock(x), y).backward()
+        for a, b in zip(ours.module.parameters(), stock.module.parameters()):
+            assert torch.allclose(a.grad, b.grad, atol=1e-6), f"step {step}"
+        opt_a.step()
+        opt_b.step()
+    assert len(ours.reducer.buckets) > 1
+    flat = torch.cat([p.detach().reshape(-1) for p in ours.module.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    # BN running stats follow rank 0 (buffer broadcast every forward)
+    rm = ours.module[1].running_mean.clone()
+    rms = [torch.empty_like(rm) for _ in range(world)]
+    ours(torch.randn(4, 3, 8, 8, generator=g))  # triggers the broadcast
+    dist.all_gather(rms, ours.module[1].running_mean.clone())
+    torch.save({"ok": True}, os.path.join(tmp, f"ok{rank}.pt"))
+    shutdown(env)
+
+
+def _worker_trainer(rank, world, port, tmp):
+    _init(rank, world, port)
+    from pytorch_distributed_training_amd.train import TrainConfig, Trainer
+
+    cfg = TrainConfig(distributed=True, use_cpu=True, model="resnet18", dataset="synthetic", dataset_length=64,
+                      batch_size=8, num_workers=0, learning_rate=1e-3, progress=False, log_every=1,
+                      checkpoint_path=os.path.join(tmp, "model.pt"), evaluate=True)
+    tr = Trainer(cfg)
+    res = tr.fit()
+    assert res.steps == 4  # 64 samples / (8 per rank * 2 ranks)
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.raw_model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    torch.save({"steps": res.steps, "acc": res.eval_accuracy}, os.path.join(tmp, f"res{rank}.pt"))
+    tr.close()
+
+
+@pytest.mark.slow
+def test_reducer_matches_stock_ddp_on_gloo(tmp_path, free_port):
+    mp.spawn(_worker_parity, args=(2, free_port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0.pt").exists() and (tmp_path / "ok1.pt").exists()
+
+
+@pytest.mark.slow
+def test_resnet18_trainer_two_ranks_checkpoint_rank0_only(tmp_path, free_port):
+    mp.spawn(_worker_trainer, args=(2, free_port, str(tmp_path)), nprocs=2, join=True)
+    sd = torch.load(tmp_path / "model.pt", weights_only=True)
+    assert "conv1.weight" in sd and "layer4.1.bn2.running_var" in sd and "fc.bias" in sd
+    assert not any(k.startswith("module.") for k in sd)
+    assert sd["conv1.weight"].shape == (64, 3, 7, 7) and sd["conv1.weight"].is_contiguous()
+    assert (tmp_path / "model.pt.resume").exists()
+    r0 = torch.load(tmp_path / "res0.pt")
+    r1 = torch.load(tmp_path / "res1.pt")
+    assert r0["acc"] == r1["acc"]

@@ -1,0 +1,208 @@
+"""Reducer core + loopback fabric: ranks are threads of this process (no process group, no GPU)."""
+import threading
+
+import pytest
+import torch
+import torch.nn as nn
+
+from pytorch_distributed_training_amd.parallel import (
+    BucketedDataParallel,
+    GradReducer,
+    LoopbackFabric,
+    LoopbackTransport,
+)
+
+
+def _mlp(seed=0):
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 4))
+
+
+def _run_ranks(world, fn):
+    errs, out = [], [None] * world
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except Exception as e:  # pragma: no cover - surfaced below
+            errs.append((r, e))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank thread hung"
+    if errs:
+        raise errs[0][1]
+    return out
+
+
+def test_fabric_allreduce_mean_and_sum():
+    world = 4
+    fab = LoopbackFabric(world)
+
+    def fn(r):
+        t = torch.full((1001,), float(r + 1))
+        fab.allreduce_(r, t, average=True)
+        u = torch.arange(10, dtype=torch.float32) * (r + 1)
+        fab.allreduce_(r, u, average=False)
+        return t, u
+
+    for t, u in _run_ranks(world, fn):
+        assert torch.allclose(t, torch.full((1001,), 2.5))
+        assert torch.allclose(u, torch.arange(10, dtype=torch.float32) * 10)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduced_grads_equal_large_batch_grads(world):
+    torch.manual_seed(1)
+    x = torch.randn(world * 8, 16)
+    y = torch.randint(0, 4, (world * 8,))
+    ref = _mlp()
+    nn.functional.cross_entropy(ref(x), y).backward()
+    ref_grads = [p.grad.clone() for p in ref.parameters()]
+    fab = LoopbackFabric(world)
+    models = [_mlp() for _ in range(world)]
+
+    def fn(r):
+        m = models[r]
+        tr = LoopbackTransport(fab, r)
+        red = GradReducer(m.parameters(), tr, bucket_mb=0.01, first_bucket_mb=0.001)
+        xs, ys = x[r * 8:(r + 1) * 8], y[r * 8:(r + 1) * 8]
+        nn.functional.cross_entropy(m(xs), ys).backward()
+        return [p.grad.clone() for p in m.parameters()], len(red.buckets), tr.collectives
+
+    for grads, n_buckets, n_coll in _run_ranks(world, fn):
+        assert n_buckets > 1 and n_coll == n_buckets
+        for g, rg in zip(grads, ref_grads):
+            assert torch.allclose(g, rg, atol=1e-6)
+
+
+def test_grads_are_bucket_views_and_zero_grad_keeps_them():
+    fab = LoopbackFabric(1)
+    m = _mlp()
+    red = GradReducer(m.parameters(), LoopbackTransport(fab, 0))
+    for p, v in zip(red.params, red.views):
+        assert p.grad.data_ptr() == v.data_ptr()
+    m(torch.randn(4, 16)).sum().backward()
+    assert any(float(b.abs().sum()) > 0 for b in red.buckets)
+    red.zero_grad()
+    assert all(float(b.abs().sum()) == 0 for b in red.buckets)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))
+
+
+def test_set_to_none_grads_are_folded_back():
+    fab = LoopbackFabric(1)
+    m = _mlp()
+    red = GradReducer(m.parameters(), LoopbackTransport(fab, 0))
+    for p in m.parameters():
+        p.grad = None
+    m(torch.randn(4, 16)).sum().backward()
+    for p, v in zip(red.params, red.views):
+        assert p.grad.data_ptr() == v.data_ptr()
+        assert float(v.abs().sum()) > 0
+
+
+def test_unused_parameters_are_reduced_as_zero():
+    world = 2
+    fab = LoopbackFabric(world)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.a = nn.Linear(4, 4)
+            self.unused = nn.Linear(4, 4)
+
+        def forward(self, x):
+            return self.a(x)
+
+    models = [Net() for _ in range(world)]
+
+    def fn(r):
+        m = models[r]
+        red = GradReducer(m.parameters(), LoopbackTransport(fab, r), bucket_mb=0.0001, first_bucket_mb=0.0001)
+        m(torch.ones(2, 4) * (r + 1)).sum().backward()
+        return red.unused_last, m.a.weight.grad.clone(), m.unused.weight.grad.clone()
+
+    for unused, ga, gu in _run_ranks(world, fn):
+        assert unused == 2
+        assert torch.allclose(ga, torch.full((4, 4), 3.0))  # mean of 2 and 4
+        assert float(gu.abs().sum()) == 0
+
+
+def test_no_sync_accumulates_then_reduces_sum():
+    world = 2
+    fab = LoopbackFabric(world)
+
+    models = [_mlp() for _ in range(world)]
+
+    def fn(r):
+        m = models[r]
+        tr = LoopbackTransport(fab, r)
+        red = GradReducer(m.parameters(), tr)
+        x = torch.ones(2, 16) * (r + 1)
+        with red.no_sync():
+            m(x).sum().backward()
+        assert tr.collectives == 0
+        local = [p.grad.clone() for p in m.parameters()]
+        m(x).sum().backward()
+        return local, [p.grad.clone() for p in m.parameters()]
+
+    outs = _run_ranks(world, fn)
+    for i in range(len(outs[0][0])):
+        expected = (2 * outs[0][0][i] + 2 * outs[1][0][i]) / 2
+        for r in range(world):
+            assert torch.allclose(outs[r][1][i], expected, atol=1e-5)
+
+
+def test_rebuild_after_first_iteration_keeps_results_correct():
+    world = 2
+    fab = LoopbackFabric(world)
+
+    class Net(nn.Module):  # gradients become ready in an order different from reverse registration
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.late = nn.Linear(8, 8)
+            self.early = nn.Linear(8, 8)
+
+        def forward(self, x):
+            return self.late(self.early(x))
+
+    models = [Net() for _ in range(world)]
+
+    def fn(r):
+        m = models[r]
+        red = GradReducer(m.parameters(), LoopbackTransport(fab, r), bucket_mb=0.0002, first_bucket_mb=0.0002)
+        before = list(red.plan.bucket_of)
+        outs = []
+        for it in range(3):
+            red.zero_grad()
+            m(torch.ones(2, 8) * (r + 1 + it)).sum().backward()
+            outs.append([p.grad.clone() for p in m.parameters()])
+        return before, list(red.plan.bucket_of), outs
+
+    res = _run_ranks(world, fn)
+    assert res[0][0] != res[0][1], "bucket assignment should follow the observed ready order"
+    assert res[0][1] == res[1][1]
+    for it in range(3):
+        for a, b in zip(res[0][2][it], res[1][2][it]):
+            assert torch.allclose(a, b)
+
+
+def test_wrapper_broadcasts_initial_state_and_strips_prefix():
+    world = 2
+    fab = LoopbackFabric(world)
+
+    models = [_mlp(seed=r) for r in range(world)]  # different init per rank
+
+    def fn(r):
+        m = models[r]
+        w = BucketedDataParallel(m, LoopbackTransport(fab, r))
+        return {k: v.clone() for k, v in w.state_dict().items()}
+
+    sd0, sd1 = _run_ranks(world, fn)
+    assert list(sd0) == list(_mlp().state_dict())
+    ref = _mlp(seed=0).state_dict()
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]) and torch.equal(sd0[k], ref[k])

@@ -1,0 +1,115 @@
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_distributed_training_amd.data import CIFAR10, DeviceSyntheticLoader, SyntheticImageDataset, build_dataset
+from pytorch_distributed_training_amd.utils.meter import AverageMeter, ThroughputMeter
+from pytorch_distributed_training_amd.utils.timers import ChromeTrace, StepTimer
+from pytorch_distributed_training_amd.utils.watchdog import GracefulStop, StepWatchdog, maybe_inject_fault
+
+
+def test_throughput_meter_excludes_warmup_and_counts_global_samples():
+    t = [0.0]
+    m = ThroughputMeter(world_size=4, warmup_steps=2, clock=lambda: t[0])
+    m.start()
+    for _ in range(2):
+        t[0] += 5.0  # slow warm-up steps
+        m.step(8)
+    for _ in range(10):
+        t[0] += 0.5
+        m.step(8)
+    m.stop()
+    assert m.timed_steps == 10 and m.timed_samples == 10 * 8 * 4
+    assert m.elapsed == pytest.approx(5.0)
+    assert m.samples_per_sec == pytest.approx(64.0)
+    assert m.ms_per_step == pytest.approx(500.0)
+    assert ThroughputMeter.scaling_efficiency(720.0, 8, 100.0) == pytest.approx(0.9)
+
+
+def test_average_meter():
+    a = AverageMeter()
+    a.update(1.0, 2)
+    a.update(4.0, 1)
+    assert a.avg == pytest.approx(2.0) and a.last == 4.0
+
+
+def test_step_timer_and_trace(tmp_path):
+    st = StepTimer(torch.device("cpu"))
+    with st.phase("fwd"):
+        time.sleep(0.01)
+    assert st.summary()["fwd"]["count"] == 1 and "fwd" in st.format()
+    tr = ChromeTrace()
+    with tr.span("x", step=1):
+        pass
+    tr.instant("mark")
+    p = tr.dump(str(tmp_path / "t" / "trace.json"))
+    assert os.path.getsize(p) > 0
+
+
+def test_watchdog_fires_and_stays_quiet_when_beating():
+    fired = []
+    w = StepWatchdog(0.05, on_timeout=lambda: fired.append(1), poll_s=0.01).start()
+    time.sleep(0.3)
+    w.stop()
+    assert fired and w.fired
+    fired2 = []
+    w2 = StepWatchdog(0.2, on_timeout=lambda: fired2.append(1), poll_s=0.01).start()
+    for i in range(10):
+        time.sleep(0.02)
+        w2.beat(i)
+    w2.stop()
+    assert not fired2
+
+
+def test_graceful_stop_records_signal():
+    import signal
+
+    g = GracefulStop(signals=(signal.SIGUSR1,)).install()
+    os.kill(os.getpid(), signal.SIGUSR1)
+    time.sleep(0.05)
+    g.uninstall()
+    assert g.requested and g.signum == signal.SIGUSR1
+
+
+def test_fault_injection_raise(monkeypatch):
+    monkeypatch.setenv("PDT_FAULT_INJECT", "1:3:raise")
+    maybe_inject_fault(0, 3)
+    maybe_inject_fault(1, 2)
+    with pytest.raises(RuntimeError):
+        maybe_inject_fault(1, 3)
+
+
+def test_cifar10_binary_reader(tmp_path):
+    d = tmp_path / "cifar-10-batches-bin"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    rec = rng.integers(0, 256, size=(20, 3073), dtype=np.uint8)
+    rec[:, 0] = rng.integers(0, 10, size=20)
+    rec.tofile(d / "test_batch.bin")
+    ds = CIFAR10(str(tmp_path), train=False)
+    assert len(ds) == 20 and len(ds.classes) == 10
+    x, y = ds[3]
+    assert x.shape == (3, 32, 32) and x.dtype == torch.float32 and 0 <= float(x.min()) and float(x.max()) <= 1
+    assert y == int(rec[3, 0])
+    assert torch.allclose(x, torch.from_numpy(rec[3, 1:].reshape(3, 32, 32).astype(np.float32) / 255))
+    ds2, desc = build_dataset("auto", str(tmp_path))
+    assert isinstance(ds2, CIFAR10) and "CIFAR-10" in desc
+
+
+def test_dataset_fallback_and_errors(tmp_path):
+    ds, desc = build_dataset("auto", str(tmp_path / "nothing"))
+    assert isinstance(ds, SyntheticImageDataset) and "synthetic" in desc and len(ds) == 10000
+    with pytest.raises(FileNotFoundError):
+        build_dataset("cifar10", str(tmp_path / "nothing"))
+    lm, _ = build_dataset("synthetic", "", model_kind="lm", seq_len=16, vocab_size=100, length=8)
+    a, b = lm[0]
+    assert a.shape == (16,) and torch.equal(a[1:], b[:-1])
+
+
+def test_device_synthetic_loader_cycles():
+    ld = DeviceSyntheticLoader(lambda i: (torch.full((2,), i), torch.zeros(2)), steps=5, n_resident=2)
+    assert len(ld) == 5
+    assert [int(x[0]) for x, _ in ld] == [0, 1, 0, 1, 0]
