@@ -1,0 +1,164 @@
+"""Headline benchmark: ResNet-50, 224x224, bf16, synthetic data, images/sec for the whole job.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment), weak scaling: the
+per-GPU batch is fixed, so the global batch is ``batch x N``.  Every timed step is a complete
+training step: forward, loss, backward with the bucketed gradient all-reduce overlapped, and the
+fused optimizer step.  Rank 0 prints one JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--model", type=str, default="resnet50")
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--seq-len", type=int, default=1024)
+    ap.add_argument("--optimizer", type=str, default="")
+    ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--cpu", action="store_true", help="plumbing check on CPU/gloo (not a valid benchmark)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.data import synthetic_image_batches, synthetic_token_batches
+    from pytorch_distributed_training_amd.models import MODELS, build_model
+    from pytorch_distributed_training_amd.optim import build_optimizer
+    from pytorch_distributed_training_amd.parallel import init_distributed, shutdown, wrap_data_parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env = init_distributed(world > 1, use_cpu=args.cpu)
+    if env.world_size != args.gpus and env.is_main:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {env.world_size}", file=sys.stderr)
+    dev = env.device
+    on_gpu = dev.type == "cuda"
+    torch.manual_seed(1234)
+    spec = MODELS[args.model]
+    is_lm = spec.kind == "lm"
+    model = build_model(args.model, 1000, args.image_size).to(dev)
+    if on_gpu:
+        model = model.to(memory_format=torch.channels_last)
+    raw = model
+    if env.distributed:
+        model = wrap_data_parallel(model, env, bucket_mb=args.bucket_mb)
+    opt_name = args.optimizer or ("adamw" if (is_lm or args.model.startswith("vit")) else "sgd")
+    lr = 3e-4 if opt_name != "sgd" else 0.1
+    wd = 0.1 if opt_name == "adamw" else 1e-4
+    optimizer = build_optimizer([p for p in raw.parameters() if p.requires_grad], opt_name, lr, wd, 0.9)
+
+    # two device-resident synthetic batches, alternated
+    if is_lm:
+        make = synthetic_token_batches(args.batch_size, args.seq_len, raw.vocab_size, dev, seed=env.rank)
+        batches = [make(i) for i in range(2)]
+    else:
+        make = synthetic_image_batches(args.batch_size, args.image_size, 1000, "cpu", seed=env.rank)
+        batches = []
+        for i in range(2):
+            x, y = make(i)
+            x = x.to(dev)
+            x = ops.to_device_layout(x, torch.bfloat16) if on_gpu else x
+            batches.append((x, y.to(dev)))
+
+    def zero_grad():
+        if env.distributed:
+            model.reducer.zero_grad()
+        else:
+            optimizer.zero_grad(set_to_none=False)
+
+    def step(i):
+        a, b = batches[i % 2]
+        if is_lm:
+            loss = model(a, b)
+        else:
+            loss = ops.softmax_cross_entropy(model(a), b)
+        loss.backward()
+        optimizer.step()
+        zero_grad()
+        return loss
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        if env.distributed:
+            dist.barrier(device_ids=[dev.index]) if env.backend == "nccl" else dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
+    model.train()
+    zero_grad()
+    for i in range(args.warmup):
+        loss = step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    if env.distributed:
+        if env.backend == "gloo":
+            t = t.to(torch.float32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+
+    per_step_samples = args.batch_size * env.world_size
+    unit_scale = args.seq_len if is_lm else 1
+    value = per_step_samples * unit_scale * args.steps / elapsed
+    if env.is_main:
+        out = {
+            "metric": ("tokens/sec (whole job) " if is_lm else "images/sec (whole node) ")
+            + f"{args.model} {'seq ' + str(args.seq_len) if is_lm else str(args.image_size) + '^2'} bf16 training",
+            "value": round(value, 2),
+            "unit": "tokens/s" if is_lm else "images/s",
+            "n_gpus": env.world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if on_gpu else "fp32",
+            "data": "synthetic (device-resident random batches, random-init weights)",
+            "config": {
+                "model": args.model,
+                "global_batch": per_step_samples,
+                "per_gpu_batch": args.batch_size,
+                "seq_len": args.seq_len if is_lm else None,
+                "image_size": None if is_lm else args.image_size,
+                "optimizer": opt_name,
+                "parallelism": f"dp{env.world_size}",
+                "bucket_mb": args.bucket_mb,
+            },
+            "final_loss": round(final_loss, 4),
+        }
+        print(json.dumps(out), flush=True)
+    if env.distributed:
+        model.reducer.close()
+    shutdown(env)
+
+
+if __name__ == "__main__":
+    main()

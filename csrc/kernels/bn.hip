@@ -1,0 +1,561 @@
+// Fused BatchNorm kernels for NHWC bf16 activations (training and inference).
+//
+// Forward:  the convolution epilogue has already accumulated per-channel (sum, sumsq) of its output
+//           into PDT_STAT_SLOTS slots.  bn_finalize folds the slots into mean / rstd / scale / shift
+//           and updates the running statistics; bn_act / bn_add_relu / bn_relu_maxpool then apply
+//           y*scale + shift (+ReLU, +residual, +3x3/2 max-pool) in one pass.
+// Backward: bn_bwd_reduce forms dz = dout * [out > 0] on the fly and accumulates sum(dz) and
+//           sum(dz * xhat) per channel (optionally for a second BatchNorm sharing dz: the projected
+//           shortcut); bn_bwd_finalize turns them into dgamma, dbeta and three per-channel
+//           coefficients; bn_bwd_apply writes dy = A*dz + B*y + C (and dz itself for the identity
+//           branch) in one pass.
+// All element-wise passes move 16 bytes (8 channels) per lane.
+//
+// Role parity: the 20 BatchNorm2d + 17 ReLU + 8 residual adds + max-pool of torchvision's ResNet-18
+// as exercised by /root/reference/src/main.py:49,74,78.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// bn_finalize: slots -> per-channel constants
+//   out consts layout: [4][C] = mean, rstd, scale, shift
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ slots, int C, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   long long* num_batches, float momentum, float eps, int training,
+                                   float* __restrict__ consts) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < PDT_STAT_SLOTS; ++s) {
+            s1 += slots[(s * 2 + 0) * C + c];
+            s2 += slots[(s * 2 + 1) * C + c];
+        }
+        mean = s1 / count;
+        var = fmaxf(s2 / count - mean * mean, 0.f);
+        if (running_mean != nullptr) {
+            const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            if (c == 0 && num_batches != nullptr) *num_batches += 1;
+        }
+    } else {
+        mean = running_mean[c];
+        var = running_var[c];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float g = gamma != nullptr ? gamma[c] : 1.f, b = beta != nullptr ? beta[c] : 0.f;
+    consts[0 * C + c] = mean;
+    consts[1 * C + c] = rstd;
+    consts[2 * C + c] = g * rstd;
+    consts[3 * C + c] = b - mean * g * rstd;
+}
+
+PDT_API int pdt_bn_finalize(const float* slots, int C, float count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
+                            int training, float* consts, void* stream) {
+    if (C <= 0 || (!training && (running_mean == nullptr || running_var == nullptr))) return -1;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(pdt_cdiv(C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), slots, C,
+                       count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, training, consts);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise forward:  out = act(y*scale + shift [+ ident | + ident*iscale + ishift])
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+template <bool RELU, int IDENT>  // IDENT: 0 none, 1 plain tensor, 2 tensor with its own scale/shift
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ consts,
+                                                          const bf16* __restrict__ ident,
+                                                          const float* __restrict__ iconsts, bf16* __restrict__ out,
+                                                          long long nvec, int C) {
+    const int cvec = C >> 3;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int c = static_cast<int>(v % cvec) << 3;
+        float sc[8], sh[8];
+        load8f(consts + 2 * C + c, sc);
+        load8f(consts + 3 * C + c, sh);
+        const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + v * 8);
+        float z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = bf16_to_f32(yv[e]) * sc[e] + sh[e];
+        if (IDENT == 1) {
+            const bf16x8 iv = *reinterpret_cast<const bf16x8*>(ident + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] += bf16_to_f32(iv[e]);
+        } else if (IDENT == 2) {
+            float isc[8], ish[8];
+            load8f(iconsts + 2 * C + c, isc);
+            load8f(iconsts + 3 * C + c, ish);
+            const bf16x8 iv = *reinterpret_cast<const bf16x8*>(ident + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] += bf16_to_f32(iv[e]) * isc[e] + ish[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(RELU ? fmaxf(z[e], 0.f) : z[e]);
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+    }
+}
+
+static inline int ew_grid(long long nvec) {
+    long long g = (nvec + 255) / 256;
+    return static_cast<int>(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+PDT_API int pdt_bn_apply_fwd(const void* y, const float* consts, const void* ident, const float* iconsts, void* out,
+                             long long numel, int C, int relu, void* stream) {
+    if (C <= 0 || (C % 8) != 0 || numel <= 0 || (numel % C) != 0) return -1;
+    const long long nvec = numel / 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16* yy = static_cast<const bf16*>(y);
+    const bf16* id = static_cast<const bf16*>(ident);
+    bf16* o = static_cast<bf16*>(out);
+    const dim3 g(ew_grid(nvec)), b(256);
+    if (ident == nullptr) {
+        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 0>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 0>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+    } else if (iconsts == nullptr) {
+        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 1>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 1>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+    } else {
+        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 2>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 2>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+    }
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward reduction:  slots[S][3][C] += (sum dz, sum dz*xhat, sum dz*xhat2),  dz = dout * [out > 0]
+//   workgroup = 32 row-lanes x 8 chunks (64 channels); grid.x = row blocks, grid.y = channel groups
+// ------------------------------------------------------------------------------------------------
+template <bool MASK, bool SECOND>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                           const bf16* __restrict__ y, const float* __restrict__ consts,
+                                                           const bf16* __restrict__ y2,
+                                                           const float* __restrict__ consts2, float* slots,
+                                                           int M, int C, int rows_per_block) {
+    __shared__ float red[32][3][64];
+    const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.y * 64 + chunk * 8;
+    const bool cok = c < C;
+    float mu[8], rs[8], mu2[8], rs2[8];
+    if (cok) {
+        load8f(consts + c, mu);
+        load8f(consts + C + c, rs);
+        if (SECOND) {
+            load8f(consts2 + c, mu2);
+            load8f(consts2 + C + c, rs2);
+        }
+    }
+    float s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    if (cok) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            const size_t off = static_cast<size_t>(r) * C + c;
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + off);
+            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + off);
+            bf16x8 ov, y2v;
+            if (MASK) ov = *reinterpret_cast<const bf16x8*>(out + off);
+            if (SECOND) y2v = *reinterpret_cast<const bf16x8*>(y2 + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float dz = bf16_to_f32(dv[e]);
+                if (MASK) dz = bf16_to_f32(ov[e]) > 0.f ? dz : 0.f;
+                s1[e] += dz;
+                s2[e] += dz * (bf16_to_f32(yv[e]) - mu[e]) * rs[e];
+                if (SECOND) s3[e] += dz * (bf16_to_f32(y2v[e]) - mu2[e]) * rs2[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[rl][0][chunk * 8 + e] = s1[e];
+        red[rl][1][chunk * 8 + e] = s2[e];
+        red[rl][2][chunk * 8 + e] = s3[e];
+    }
+    __syncthreads();
+    constexpr int NS = SECOND ? 3 : 2;
+    if (threadIdx.x < NS * 64) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) t += red[r][which][col];
+        const int cc = blockIdx.y * 64 + col;
+        if (cc < C) {
+            float* slot = slots + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 3 * C;
+            __hip_atomic_fetch_add(slot + which * C + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static inline int reduce_rows_per_block(int M, int C) {
+    const long long groups = (C + 63) / 64;
+    long long blocks_x = 2048 / groups;
+    if (blocks_x < 1) blocks_x = 1;
+    long long rpb = (M + blocks_x - 1) / blocks_x;
+    rpb = (rpb + 31) / 32 * 32;
+    return static_cast<int>(rpb < 32 ? 32 : rpb);
+}
+
+// slots: zero-initialised [PDT_STAT_SLOTS][3][C]
+PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, const float* consts, const void* y2,
+                              const float* consts2, float* slots, int M, int C, void* stream) {
+    if (M <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    const int rpb = reduce_rows_per_block(M, C);
+    const dim3 g(pdt_cdiv(M, rpb), pdt_cdiv(C, 64)), b(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16 *d = static_cast<const bf16*>(dout), *o = static_cast<const bf16*>(out), *yy = static_cast<const bf16*>(y),
+               *yy2 = static_cast<const bf16*>(y2);
+    const bool mask = out != nullptr, second = y2 != nullptr;
+    if (mask && second) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
+    else if (mask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
+    else if (second) hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, true>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bn_bwd_finalize: slots -> dgamma, dbeta, coef[3][C] with dy = coef0*dz + coef1*y + coef2
+//   `which` selects the dz*xhat sum (1 = first BatchNorm, 2 = second)
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slots, int C, int which, float count,
+                                       const float* __restrict__ gamma, const float* __restrict__ consts,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sdz = 0.f, sdzx = 0.f;
+    for (int s = 0; s < PDT_STAT_SLOTS; ++s) {
+        sdz += slots[(s * 3 + 0) * C + c];
+        sdzx += slots[(s * 3 + which) * C + c];
+    }
+    const float mean = consts[c], rstd = consts[C + c];
+    const float g = gamma != nullptr ? gamma[c] : 1.f;
+    if (dgamma != nullptr) dgamma[c] = sdzx;
+    if (dbeta != nullptr) dbeta[c] = sdz;
+    const float k1 = g * rstd;
+    const float b = -k1 * rstd * sdzx / count;
+    coef[c] = k1;
+    coef[C + c] = b;
+    coef[2 * C + c] = -k1 * sdz / count - b * mean;
+}
+
+PDT_API int pdt_bn_bwd_finalize(const float* slots, int C, int which, float count, const float* gamma,
+                                const float* consts, float* dgamma, float* dbeta, float* coef, void* stream) {
+    if (C <= 0 || (which != 1 && which != 2)) return -1;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pdt_cdiv(C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), slots, C,
+                       which, count, gamma, consts, dgamma, dbeta, coef);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bn_bwd_apply:  dz = dout*[out>0];  dy = c0*dz + c1*y + c2;  optional dz store; optional second dy2
+// ------------------------------------------------------------------------------------------------
+template <bool MASK, bool WRITE_DZ, bool SECOND>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                          const bf16* __restrict__ y, const float* __restrict__ coef,
+                                                          bf16* __restrict__ dy, bf16* __restrict__ dz_out,
+                                                          const bf16* __restrict__ y2, const float* __restrict__ coef2,
+                                                          bf16* __restrict__ dy2, long long nvec, int C) {
+    const int cvec = C >> 3;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int c = static_cast<int>(v % cvec) << 3;
+        float k0[8], k1[8], k2[8];
+        load8f(coef + c, k0);
+        load8f(coef + C + c, k1);
+        load8f(coef + 2 * C + c, k2);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + v * 8);
+        const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + v * 8);
+        float dz[8];
+        if (MASK) {
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(out + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dz[e] = bf16_to_f32(ov[e]) > 0.f ? bf16_to_f32(dv[e]) : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dz[e] = bf16_to_f32(dv[e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(k0[e] * dz[e] + k1[e] * bf16_to_f32(yv[e]) + k2[e]);
+        *reinterpret_cast<bf16x8*>(dy + v * 8) = o;
+        if (WRITE_DZ) {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = f32_to_bf16(dz[e]);
+            *reinterpret_cast<bf16x8*>(dz_out + v * 8) = z;
+        }
+        if (SECOND) {
+            float q0[8], q1[8], q2[8];
+            load8f(coef2 + c, q0);
+            load8f(coef2 + C + c, q1);
+            load8f(coef2 + 2 * C + c, q2);
+            const bf16x8 y2v = *reinterpret_cast<const bf16x8*>(y2 + v * 8);
+            bf16x8 o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = f32_to_bf16(q0[e] * dz[e] + q1[e] * bf16_to_f32(y2v[e]) + q2[e]);
+            *reinterpret_cast<bf16x8*>(dy2 + v * 8) = o2;
+        }
+    }
+}
+
+PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, const float* coef, void* dy, void* dz_out,
+                             const void* y2, const float* coef2, void* dy2, long long numel, int C, void* stream) {
+    if (C <= 0 || (C % 8) != 0 || numel <= 0 || (numel % C) != 0) return -1;
+    if (dz_out != nullptr && y2 != nullptr) return -1;  // identity is either plain (needs dz) or projected (needs dy2)
+    const long long nvec = numel / 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 g(ew_grid(nvec)), b(256);
+    const bf16 *d = static_cast<const bf16*>(dout), *o = static_cast<const bf16*>(out), *yy = static_cast<const bf16*>(y),
+               *yy2 = static_cast<const bf16*>(y2);
+    bf16 *pdy = static_cast<bf16*>(dy), *pdz = static_cast<bf16*>(dz_out), *pdy2 = static_cast<bf16*>(dy2);
+    const bool mask = out != nullptr;
+#define PDT_APPLY(MK, WZ, SC) \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, WZ, SC>), g, b, 0, s, d, o, yy, coef, pdy, pdz, yy2, coef2, pdy2, nvec, C)
+    if (mask) {
+        if (dz_out != nullptr) PDT_APPLY(true, true, false);
+        else if (y2 != nullptr) PDT_APPLY(true, false, true);
+        else PDT_APPLY(true, false, false);
+    } else {
+        if (dz_out != nullptr) PDT_APPLY(false, true, false);
+        else if (y2 != nullptr) PDT_APPLY(false, false, true);
+        else PDT_APPLY(false, false, false);
+    }
+#undef PDT_APPLY
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem tail: out = maxpool3x3/s2/p1(relu(y*scale + shift)), idx = winning tap (0..8) per channel
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ consts,
+                                                                 bf16* __restrict__ out, uint8_t* __restrict__ idx,
+                                                                 int NB, int H, int W, int C, int Ho, int Wo) {
+    const int cvec = C >> 3;
+    const long long nvec = static_cast<long long>(NB) * Ho * Wo * cvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int cv = static_cast<int>(v % cvec);
+        long long pix = v / cvec;
+        const int wo = static_cast<int>(pix % Wo);
+        pix /= Wo;
+        const int ho = static_cast<int>(pix % Ho);
+        const int n = static_cast<int>(pix / Ho);
+        const int c = cv << 3;
+        float sc[8], sh[8];
+        load8f(consts + 2 * C + c, sc);
+        load8f(consts + 3 * C + c, sh);
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            best[e] = -1.f;  // relu output is >= 0, so any in-bounds tap wins over this
+            bi[e] = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int h = ho * 2 - 1 + r;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int w = wo * 2 - 1 + s;
+                if (w < 0 || w >= W) continue;
+                const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + ((static_cast<size_t>(n) * H + h) * W + w) * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = fmaxf(bf16_to_f32(yv[e]) * sc[e] + sh[e], 0.f);
+                    if (z > best[e]) {
+                        best[e] = z;
+                        bi[e] = r * 3 + s;
+                    }
+                }
+            }
+        }
+        bf16x8 o;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = f32_to_bf16(best[e]);
+            if (e < 4) lo |= static_cast<uint32_t>(bi[e]) << (8 * e);
+            else hi |= static_cast<uint32_t>(bi[e]) << (8 * (e - 4));
+        }
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+        *reinterpret_cast<uint2*>(idx + v * 8) = make_uint2(lo, hi);
+    }
+}
+
+PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* consts, void* out, void* idx, int NB, int H, int W, int C,
+                                    void* stream) {
+    if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long nvec = static_cast<long long>(NB) * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_grid(nvec)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(y), consts, static_cast<bf16*>(out), static_cast<uint8_t*>(idx), NB, H, W,
+                       C, Ho, Wo);
+    return pdt_launch_status();
+}
+
+// Backward of the stem tail, fused with the BatchNorm reduction:
+//   dz[n,h,w,c] = [z > 0] * sum over pooling windows whose winning tap is (h,w) of dout
+//   slots[S][3][C] += (sum dz, sum dz*xhat, 0)
+// One thread per (input pixel, 8 channels); workgroup = 32 pixels x 8 chunks (64 channels).
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const bf16* __restrict__ dout,
+                                                                   const uint8_t* __restrict__ idx,
+                                                                   const bf16* __restrict__ y,
+                                                                   const float* __restrict__ consts, bf16* __restrict__ dz,
+                                                                   float* slots, int NB, int H, int W, int C, int Ho,
+                                                                   int Wo, int pix_per_block) {
+    __shared__ float red[32][2][64];
+    const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.y * 64 + chunk * 8;
+    const bool cok = c < C;
+    float mu[8], rs[8], sc[8], sh[8];
+    if (cok) {
+        load8f(consts + c, mu);
+        load8f(consts + C + c, rs);
+        load8f(consts + 2 * C + c, sc);
+        load8f(consts + 3 * C + c, sh);
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    const long long npix = static_cast<long long>(NB) * H * W;
+    const long long p0 = static_cast<long long>(blockIdx.x) * pix_per_block;
+    const long long p1 = min(npix, p0 + pix_per_block);
+    if (cok) {
+        for (long long pix = p0 + rl; pix < p1; pix += 32) {
+            const int w = static_cast<int>(pix % W);
+            const long long t = pix / W;
+            const int h = static_cast<int>(t % H);
+            const int n = static_cast<int>(t / H);
+            float g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = 0.f;
+            // windows (oh, ow) that contain (h, w): 2*oh - 1 <= h <= 2*oh + 1
+            const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;
+            const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+            for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+                if (oh >= Ho) continue;
+                const int r = h - (2 * oh - 1);
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    if (ow >= Wo) continue;
+                    const int tap = r * 3 + (w - (2 * ow - 1));
+                    const size_t o = ((static_cast<size_t>(n) * Ho + oh) * Wo + ow) * C + c;
+                    const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
+                    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t word = e < 4 ? iv.x : iv.y;
+                        const int win = (word >> (8 * (e & 3))) & 0xff;
+                        if (win == tap) g[e] += bf16_to_f32(dv[e]);
+                    }
+                }
+            }
+            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + pix * C + c);
+            bf16x8 zo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float yf = bf16_to_f32(yv[e]);
+                const float d = (yf * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+                zo[e] = f32_to_bf16(d);
+                s1[e] += d;
+                s2[e] += d * (yf - mu[e]) * rs[e];
+            }
+            *reinterpret_cast<bf16x8*>(dz + pix * C + c) = zo;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[rl][0][chunk * 8 + e] = s1[e];
+        red[rl][1][chunk * 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) t += red[r][which][col];
+        const int cc = blockIdx.y * 64 + col;
+        if (cc < C) {
+            float* slot = slots + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 3 * C;
+            __hip_atomic_fetch_add(slot + which * C + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+PDT_API int pdt_maxpool_bn_bwd_reduce(const void* dout, const void* idx, const void* y, const float* consts, void* dz,
+                                      float* slots, int NB, int H, int W, int C, void* stream) {
+    if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long npix = static_cast<long long>(NB) * H * W;
+    if (npix >= (1ll << 31)) return -1;
+    const int ppb = reduce_rows_per_block(static_cast<int>(npix), C);
+    const dim3 g(pdt_cdiv(npix, ppb), pdt_cdiv(C, 64)), b(256);
+    hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, g, b, 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(dout), static_cast<const uint8_t*>(idx), static_cast<const bf16*>(y), consts,
+                       static_cast<bf16*>(dz), slots, NB, H, W, C, Ho, Wo, ppb);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global average pool over H*W (NHWC):  out[n][c] = mean_hw a[n][hw][c];  backward broadcasts g/HW
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16* __restrict__ a, bf16* __restrict__ out, int NB, int HW,
+                                                         int C) {
+    const int cvec = C >> 3;
+    const long long nvec = static_cast<long long>(NB) * cvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int n = static_cast<int>(v / cvec), c = static_cast<int>(v % cvec) << 3;
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        for (int i = 0; i < HW; ++i) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + (static_cast<size_t>(n) * HW + i) * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf16_to_f32(x[e]);
+        }
+        bf16x8 o;
+        const float inv = 1.f / HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(s[e] * inv);
+        *reinterpret_cast<bf16x8*>(out + static_cast<size_t>(n) * C + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16* __restrict__ g, bf16* __restrict__ da, int NB, int HW,
+                                                         int C) {
+    const int cvec = C >> 3;
+    const long long nvec = static_cast<long long>(NB) * HW * cvec;
+    const float inv = 1.f / HW;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int c = static_cast<int>(v % cvec) << 3;
+        const int n = static_cast<int>(v / (static_cast<long long>(HW) * cvec));
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(g + static_cast<size_t>(n) * C + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(bf16_to_f32(x[e]) * inv);
+        *reinterpret_cast<bf16x8*>(da + v * 8) = o;
+    }
+}
+
+PDT_API int pdt_avgpool_fwd(const void* a, void* out, int NB, int HW, int C, void* stream) {
+    if (NB <= 0 || HW <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_grid(static_cast<long long>(NB) * (C / 8))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(a), static_cast<bf16*>(out), NB, HW, C);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_avgpool_bwd(const void* g, void* da, int NB, int HW, int C, void* stream) {
+    if (NB <= 0 || HW <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(static_cast<long long>(NB) * HW * (C / 8))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(g), static_cast<bf16*>(da), NB, HW, C);
+    return pdt_launch_status();
+}

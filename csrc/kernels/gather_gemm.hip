@@ -1,0 +1,492 @@
+// Implicit-GEMM convolution / linear layer on MFMA (gfx950, bf16 in, fp32 accumulate).
+//
+//   Out[m][n] = sum_t sum_c A(m, t, c) * B[n][woff_t + c]        (+ bias[n])
+//
+// A row m is an output pixel (img, a, b) of this launch; for tap t its operand is the C-vector
+// of input pixel (a*istr + dh_t, b*istr + dw_t) of image img, or zeros when that pixel is outside
+// the input.  The tap table makes one kernel serve
+//   * forward convolution of any stride (taps = kernel window),
+//   * data gradient (taps = the window positions that reach an output-parity class, B = weights
+//     transposed to [Cin][R][S][Cout]), written with an output stride for stride-2 layers,
+//   * plain GEMM / nn.Linear (one tap, 1x1 "image").
+// Activations are NHWC, so a tap's operand is contiguous and is fetched with 16-byte loads.
+//
+// Tiling: BM x BN output tile per 256-thread workgroup (4 waves), K-step 64, operands staged
+// through LDS in an XOR-swizzled [row][64] layout that makes the ds_read_b128 fragment reads
+// conflict-free, global->register prefetch of step k+1 issued before the MFMAs of step k,
+// one barrier per K-step (two LDS buffers).  The MFMA is issued with the weight fragment as the
+// first operand, so each lane ends up holding four consecutive output channels of one pixel:
+// results are packed to bf16x4, staged through LDS and written as whole 16-byte row segments.
+// The epilogue also produces per-channel partial sums / sums of squares of the stored values
+// (BatchNorm statistics) so no extra pass over the output is needed.
+//
+// Role parity: the cuDNN/cuBLAS kernels behind `net(imgs)` / `losses.backward()` at
+// /root/reference/src/main.py:74,78.
+#include "common.h"
+
+#define GG_MAX_TAPS 49
+#define GG_BK 64
+
+struct GatherGemmArgs {
+    const bf16* A;
+    const bf16* B;
+    bf16* Out;
+    float* stats;       // [PDT_STAT_SLOTS][2][N] zero-initialised (sum, sumsq) accumulators, or nullptr
+    const float* bias;  // [N] or nullptr
+    int M, N, ldb, ldo, C, T;
+    int Hin, Win, istr;
+    int Hout, Wout, ostr, oph, opw;
+    FastDiv div_ab;  // divide by OA*OB
+    FastDiv div_b;   // divide by OB
+    int OA, OB;
+    int tap_dh[GG_MAX_TAPS];
+    int tap_dw[GG_MAX_TAPS];
+    int tap_woff[GG_MAX_TAPS];
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p) {
+    constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
+    constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
+    constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sA = reinterpret_cast<bf16*>(smem);  // [2][BM][64]
+    bf16* sB = sA + 2 * BM * GG_BK;            // [2][BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread loader state
+    const int chunk = tid & 7, lrow = tid >> 3;
+    int a_pix[AP], a_h[AP], a_w[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const uint32_t img = fastdiv(m, p.div_ab);
+            const uint32_t rem = m - img * (p.OA * p.OB);
+            const uint32_t a = fastdiv(rem, p.div_b);
+            const uint32_t b = rem - a * p.OB;
+            a_pix[i] = img * (p.Hin * p.Win);
+            a_h[i] = a * p.istr;
+            a_w[i] = b * p.istr;
+        } else {
+            a_pix[i] = 0;
+            a_h[i] = -(1 << 24);
+            a_w[i] = 0;
+        }
+    }
+    uint32_t b_off[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_ok[i] = n < p.N;
+        b_off[i] = (b_ok[i] ? n : 0) * p.ldb + chunk * 8;
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int csteps = p.C / GG_BK;
+    const int nsteps = p.T * csteps;
+    bf16x8 ra[AP], rb[BP];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_step = [&](int t, int c0) {
+        const int dh = p.tap_dh[t], dw = p.tap_dw[t], woff = p.tap_woff[t] + c0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int ih = a_h[i] + dh, iw = a_w[i] + dw;
+            const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                            static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+            const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.C + c0 + chunk * 8;
+            ra[i] = ok ? *reinterpret_cast<const bf16x8*>(p.A + off) : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            rb[i] = b_ok[i] ? *reinterpret_cast<const bf16x8*>(p.B + b_off[i] + woff) : zero8;
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int row = lrow + 32 * i;
+            *reinterpret_cast<bf16x8*>(sA + (buf * BM + row) * GG_BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int row = lrow + 32 * i;
+            *reinterpret_cast<bf16x8*>(sB + (buf * BN + row) * GG_BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[FM], fb[FN];
+            const int kc = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * TM + i * 16 + (lane & 15);
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + (buf * BM + row) * GG_BK + ((kc ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * TN + j * 16 + (lane & 15);
+                fb[j] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + row) * GG_BK + ((kc ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nsteps > 0) {
+        int t = 0, c0 = 0;
+        load_step(0, 0);
+        store_step(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (more) {
+                c0 += GG_BK;
+                if (c0 >= p.C) {
+                    c0 = 0;
+                    ++t;
+                }
+                load_step(t, c0);
+            }
+            compute(s & 1);
+            if (more) store_step((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: registers -> (bias) -> bf16 -> LDS -> 16-byte row segments + channel statistics
+    constexpr int LDC = BN + 8;
+    bf16* sC = reinterpret_cast<bf16*>(smem);  // [BM][LDC]; all K-loop LDS reads are behind a barrier
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int nl = wn * TN + j * 16 + (lane >> 4) * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+            const int n = n0 + nl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int ml = wm * TM + i * 16 + (lane & 15);
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(acc[i][j][e] + bv[e]);
+            *reinterpret_cast<bf16x4*>(sC + ml * LDC + nl) = v;
+        }
+    }
+    __syncthreads();
+
+    constexpr int CH = BN / 8;      // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CH;   // rows per pass
+    constexpr int NPASS = BM / RPP;
+    const int ch = tid % CH, prow = tid / CH;
+    const int ncol = n0 + ch * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = prow + ps * RPP;
+        const int m = m0 + row;
+        if (m < p.M && ncol < p.N) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+            const uint32_t img = fastdiv(m, p.div_ab);
+            const uint32_t rem = m - img * (p.OA * p.OB);
+            const uint32_t a = fastdiv(rem, p.div_b);
+            const uint32_t b = rem - a * p.OB;
+            const size_t pix = (static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw;
+            *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf16_to_f32(v[e]);
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        // Workgroup totals, then one atomic per (statistic, channel) into slot tile_m % PDT_STAT_SLOTS.
+        // Spreading over slots keeps same-address contention low; a finalize kernel folds the slots.
+        __syncthreads();  // sC fully consumed
+        float* sS = reinterpret_cast<float*>(smem);  // [RPP][2][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sS[(prow * 2 + 0) * BN + ch * 8 + e] = s1[e];
+            sS[(prow * 2 + 1) * BN + ch * 8 + e] = s2[e];
+        }
+        __syncthreads();
+        float* slot = p.stats + static_cast<size_t>(tile_m % PDT_STAT_SLOTS) * 2 * p.N;
+        for (int idx = tid; idx < 2 * BN; idx += 256) {
+            const int which = idx / BN, col = idx - which * BN;
+            float tot = 0.f;
+            for (int r = 0; r < RPP; ++r) tot += sS[(r * 2 + which) * BN + col];
+            if (n0 + col < p.N)
+                __hip_atomic_fetch_add(slot + which * p.N + n0 + col, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gather_gemm(const GatherGemmArgs& a, hipStream_t stream) {
+    const int grid = pdt_cdiv(a.M, BM) * pdt_cdiv(a.N, BN);
+    constexpr size_t lds_loop = 2ull * (BM + BN) * GG_BK * sizeof(bf16);
+    constexpr size_t lds_epi = static_cast<size_t>(BM) * (BN + 8) * sizeof(bf16);
+    constexpr size_t lds_stats = (256 / (BN / 8)) * 2ull * BN * sizeof(float);
+    constexpr size_t lds = lds_loop > lds_epi ? (lds_loop > lds_stats ? lds_loop : lds_stats)
+                                              : (lds_epi > lds_stats ? lds_epi : lds_stats);
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, stream, a);
+    return pdt_launch_status();
+}
+
+// Host entry.  Shapes are validated here; the kernel assumes them.
+//   tile: 0 = 128x128, 1 = 128x64 (narrow N), 2 = 256x128... (see switch)
+// Returns 0 on success, -1 on invalid arguments, otherwise a hipError_t.
+PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stats, const float* bias, int M, int N,
+                            int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
+                            int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
+                            const int* tap_woff, int tile, void* stream) {
+    if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0 || (C % GG_BK) != 0) return -1;
+    if ((ldo % 8) != 0 || (ldb % 8) != 0 || OA <= 0 || OB <= 0) return -1;
+    GatherGemmArgs a;
+    a.A = static_cast<const bf16*>(A);
+    a.B = static_cast<const bf16*>(B);
+    a.Out = static_cast<bf16*>(Out);
+    a.stats = stats;
+    a.bias = bias;
+    a.M = M; a.N = N; a.ldb = ldb; a.ldo = ldo; a.C = C; a.T = T;
+    a.Hin = Hin; a.Win = Win; a.istr = istr;
+    a.Hout = Hout; a.Wout = Wout; a.ostr = ostr; a.oph = oph; a.opw = opw;
+    a.OA = OA; a.OB = OB;
+    a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
+    a.div_b = make_fastdiv(OB);
+    for (int t = 0; t < T; ++t) {
+        if ((tap_woff[t] % 8) != 0) return -1;
+        a.tap_dh[t] = tap_dh[t];
+        a.tap_dw[t] = tap_dw[t];
+        a.tap_woff[t] = tap_woff[t];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (tile) {
+        case 0: return launch_gather_gemm<128, 128, 2, 2>(a, s);
+        case 1: return launch_gather_gemm<128, 64, 4, 1>(a, s);
+        case 2: return launch_gather_gemm<64, 64, 2, 2>(a, s);
+        default: return -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[n][woff_t + c] += sum_m dY[m][n] * A(m, t, c)
+//
+// The reduction runs over output pixels m, which is the slow axis of both operands, so both MFMA
+// operands are read from LDS with the transposing ds_read_b64_tr_b16 (tiles are staged exactly as
+// they sit in memory: [m][n] and [m][c]).  The M range is split across workgroups (grid.y) and the
+// fp32 partial tiles are combined with global atomic adds into a zero-initialised dW.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const bf16* dY;
+    const bf16* X;
+    float* dW;
+    int M, N, ldy, C, T, ldw;
+    int Hin, Win, istr, OA, OB;
+    FastDiv div_ab, div_b;
+    int m_per_split;
+    int tap_dh[GG_MAX_TAPS];
+    int tap_dw[GG_MAX_TAPS];
+    int tap_woff[GG_MAX_TAPS];
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+__device__ __forceinline__ bf16x8 lds_read_tr8(const bf16* base_lo, const bf16* base_hi) {
+    // two 4(k) x 16(col) transposed block reads -> this lane's 8 consecutive k of one column
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base_hi));
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int BT>  // BT x BT output tile (n x c), BT in {64, 128}
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    constexpr int KM = 64;             // pixels per K-step
+    constexpr int PITCH = BT + 16;     // bf16 elements per LDS row (pad 32 B: conflict-free transposed reads)
+    constexpr int TW = BT / 2;         // per-wave tile (2 x 2 waves)
+    constexpr int F = TW / 16;         // fragments per wave per dim
+    constexpr int CPR = BT / 8;        // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;     // rows per loader pass
+    constexpr int NP = KM / RPP;       // loader passes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sY = reinterpret_cast<bf16*>(smem);  // [2][KM][PITCH]
+    bf16* sX = sY + 2 * KM * PITCH;            // [2][KM][PITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (p.N + BT - 1) / BT, tiles_c = (p.C + BT - 1) / BT;
+    int bid = blockIdx.x;
+    const int tap = bid % p.T;  // taps fastest: neighbouring blocks re-read the same pixels from L2
+    bid /= p.T;
+    const int tc = bid % tiles_c, tn = bid / tiles_c;
+    const int n0 = tn * BT, c0 = tc * BT;
+    const int ms = blockIdx.y * p.m_per_split;
+    const int me = min(p.M, ms + p.m_per_split);
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+
+    const int chunk = tid % CPR, lrow = tid / CPR;
+    const bool y_ok = n0 + chunk * 8 < p.N;
+    const bool x_ok = c0 + chunk * 8 < p.C;
+
+    f32x4 acc[F][F];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 ry[NP], rx[NP];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_step = [&](int mbase) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int m = mbase + lrow + i * RPP;
+            const bool mok = m < me;
+            ry[i] = (mok && y_ok) ? *reinterpret_cast<const bf16x8*>(p.dY + static_cast<size_t>(m) * p.ldy + n0 + chunk * 8)
+                                  : zero8;
+            bool ok = mok && x_ok;
+            uint32_t off = 0;
+            if (ok) {
+                const uint32_t img = fastdiv(m, p.div_ab);
+                const uint32_t rem = m - img * (p.OA * p.OB);
+                const uint32_t a = fastdiv(rem, p.div_b);
+                const uint32_t b = rem - a * p.OB;
+                const int ih = static_cast<int>(a) * p.istr + dh, iw = static_cast<int>(b) * p.istr + dw;
+                ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                     static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+                off = (img * (p.Hin * p.Win) + ih * p.Win + iw) * p.C + c0 + chunk * 8;
+            }
+            rx[i] = ok ? *reinterpret_cast<const bf16x8*>(p.X + off) : zero8;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = lrow + i * RPP;
+            *reinterpret_cast<bf16x8*>(sY + (buf * KM + row) * PITCH + chunk * 8) = ry[i];
+            *reinterpret_cast<bf16x8*>(sX + (buf * KM + row) * PITCH + chunk * 8) = rx[i];
+        }
+    };
+    // Transposed fragment addressing: lane (16g + 4q + pp) supplies the address of block row q,
+    // columns 4pp..4pp+3.  Which tile row plays "k = 8g + j" is free as long as both operands agree
+    // (k is only summed over), so lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3 of each
+    // 32-row sub-step: a 32-lane half then touches 8 consecutive rows, whose 32-byte segments fall
+    // on distinct banks with the padded pitch.
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < KM / 32; ++kk) {
+            const int krow = kk * 32 + 4 * g + q;
+            bf16x8 fy[F], fx[F];
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const bf16* b0 = sY + (buf * KM + krow) * PITCH + wr * TW + i * 16 + 4 * pp;
+                fy[i] = lds_read_tr8(b0, b0 + 16 * PITCH);
+            }
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const bf16* b0 = sX + (buf * KM + krow) * PITCH + wc * TW + j * 16 + 4 * pp;
+                fx[j] = lds_read_tr8(b0, b0 + 16 * PITCH);
+            }
+#pragma unroll
+            for (int i = 0; i < F; ++i)
+#pragma unroll
+                for (int j = 0; j < F; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nsteps = (me - ms + KM - 1) / KM;
+    if (nsteps > 0) {
+        load_step(ms);
+        store_step(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (more) load_step(ms + (s + 1) * KM);
+            compute(s & 1);
+            if (more) store_step((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // D[i = n][j = c]: lane holds rows (lane>>4)*4 + e, column lane&15
+    const int woff = p.tap_woff[tap];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const int c = c0 + wc * TW + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wr * TW + i * 16 + (lane >> 4) * 4 + e;
+                if (n < p.N && c < p.C)
+                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(n) * p.ldw + woff + c, acc[i][j][e],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+}
+
+// dW must be zero (or hold a value to accumulate onto) before the call.
+PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
+                      int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
+                      int splits, int tile, void* stream) {
+    if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (C % 8) != 0 || (N % 8) != 0 || (ldy % 8) != 0)
+        return -1;
+    if (splits <= 0 || OA <= 0 || OB <= 0) return -1;
+    WgradArgs a;
+    a.dY = static_cast<const bf16*>(dY);
+    a.X = static_cast<const bf16*>(X);
+    a.dW = dW;
+    a.M = M; a.N = N; a.ldy = ldy; a.C = C; a.T = T; a.ldw = ldw;
+    a.Hin = Hin; a.Win = Win; a.istr = istr; a.OA = OA; a.OB = OB;
+    a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
+    a.div_b = make_fastdiv(OB);
+    int mps = pdt_cdiv(M, splits);
+    mps = pdt_cdiv(mps, 64) * 64;
+    a.m_per_split = mps;
+    const int gy = pdt_cdiv(M, mps);
+    for (int t = 0; t < T; ++t) {
+        a.tap_dh[t] = tap_dh[t];
+        a.tap_dw[t] = tap_dw[t];
+        a.tap_woff[t] = tap_woff[t];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (tile == 0) {
+        constexpr int BT = 128;
+        const int gx = pdt_cdiv(N, BT) * pdt_cdiv(C, BT) * T;
+        const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
+        hipLaunchKernelGGL((wgrad_kernel<BT>), dim3(gx, gy), dim3(256), lds, s, a);
+    } else if (tile == 1) {
+        constexpr int BT = 64;
+        const int gx = pdt_cdiv(N, BT) * pdt_cdiv(C, BT) * T;
+        const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
+        hipLaunchKernelGGL((wgrad_kernel<BT>), dim3(gx, gy), dim3(256), lds, s, a);
+    } else {
+        return -1;
+    }
+    return pdt_launch_status();
+}

@@ -1,0 +1,123 @@
+// Layout / precision preparation kernels.
+//   * NCHW float image batch -> NHWC bf16 (what every GPU kernel in this library reads)
+//   * stem im2col: NHWC bf16 image with few channels -> [pixels][K] patch matrix (K padded to 64)
+//     so the 7x7/2 stem convolution runs on the same MFMA GEMM as every other layer
+//   * fp32 -> bf16 cast (initial bf16 copies of the weights; later refreshed by the optimizer kernel)
+//   * weight transpose [Cout][taps][Cin] fp32 -> [Cin][taps][Cout] bf16 (operand of the data gradient)
+//
+// Role parity: the synchronous `.to(device)` upload and cuDNN's internal layout handling reached
+// from /root/reference/src/main.py:69-70,74.
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, bf16* __restrict__ out, int NB, int C,
+                                                          long long HW) {
+    const long long npix = static_cast<long long>(NB) * HW;
+    for (long long pix = blockIdx.x * 256ll + threadIdx.x; pix < npix; pix += gridDim.x * 256ll) {
+        const long long n = pix / HW, hw = pix - n * HW;
+        const T* src = x + n * C * HW + hw;
+        bf16* dst = out + pix * C;
+        for (int c = 0; c < C; ++c) dst[c] = f32_to_bf16(static_cast<float>(src[c * HW]));
+    }
+}
+
+// dtype: 0 fp32, 1 bf16 source
+PDT_API int pdt_nchw_to_nhwc_bf16(const void* x, void* out, int NB, int C, int H, int W, int dtype, void* stream) {
+    if (NB <= 0 || C <= 0 || H <= 0 || W <= 0) return -1;
+    const long long HW = static_cast<long long>(H) * W, npix = NB * HW;
+    long long g = (npix + 255) / 256;
+    g = g > 8192 ? 8192 : g;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == 0) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, s, static_cast<const float*>(x), static_cast<bf16*>(out), NB, C, HW);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(g), dim3(256), 0, s, static_cast<const bf16*>(x), static_cast<bf16*>(out), NB, C, HW);
+    return pdt_launch_status();
+}
+
+// out[m][k], m = (n, ho, wo), k = (r*S + s)*C + c for k < R*S*C, zero for the padding columns
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int NB, int H, int W,
+                                                    int C, int R, int S, int stride, int pad, int Ho, int Wo, int Kpad) {
+    const int kvec = Kpad >> 3;
+    const long long nvec = static_cast<long long>(NB) * Ho * Wo * kvec;
+    const int K = R * S * C;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int kc = static_cast<int>(v % kvec);
+        long long m = v / kvec;
+        const int wo = static_cast<int>(m % Wo);
+        m /= Wo;
+        const int ho = static_cast<int>(m % Ho);
+        const int n = static_cast<int>(m / Ho);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            float val = 0.f;
+            if (k < K) {
+                const int c = k % C, rs = k / C;
+                const int s = rs % S, r = rs / S;
+                const int ih = ho * stride - pad + r, iw = wo * stride - pad + s;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    val = bf16_to_f32(x[((static_cast<size_t>(n) * H + ih) * W + iw) * C + c]);
+            }
+            o[e] = f32_to_bf16(val);
+        }
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+    }
+}
+
+PDT_API int pdt_im2col(const void* x, void* out, int NB, int H, int W, int C, int R, int S, int stride, int pad, int Kpad,
+                       void* stream) {
+    if (NB <= 0 || C <= 0 || Kpad < R * S * C || (Kpad % 8) != 0) return -1;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    const long long nvec = static_cast<long long>(NB) * Ho * Wo * (Kpad / 8);
+    long long g = (nvec + 255) / 256;
+    g = g > 16384 ? 16384 : g;
+    hipLaunchKernelGGL(im2col_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16*>(x),
+                       static_cast<bf16*>(out), NB, H, W, C, R, S, stride, pad, Ho, Wo, Kpad);
+    return pdt_launch_status();
+}
+
+// dst[row][0..cols_dst) = bf16(src[row][0..cols_src)), zero padded (cols_dst >= cols_src)
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long rows,
+                                                      int cols_src, int cols_dst) {
+    const long long n = rows * cols_dst;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+        const long long r = i / cols_dst;
+        const int c = static_cast<int>(i - r * cols_dst);
+        dst[i] = f32_to_bf16(c < cols_src ? src[r * cols_src + c] : 0.f);
+    }
+}
+
+PDT_API int pdt_cast_pad_f32_bf16(const float* src, void* dst, long long rows, int cols_src, int cols_dst, void* stream) {
+    if (rows <= 0 || cols_src <= 0 || cols_dst < cols_src) return -1;
+    long long g = (rows * cols_dst + 255) / 256;
+    g = g > 4096 ? 4096 : g;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), src, static_cast<bf16*>(dst),
+                       rows, cols_src, cols_dst);
+    return pdt_launch_status();
+}
+
+// src fp32 [N][T][C]  ->  dst bf16 [C][T][N]   (32x32 tiles through LDS, coalesced on both sides)
+__global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int T,
+                                                         int C) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (n < N && c < C) ? src[(static_cast<size_t>(n) * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, n = n0 + tx;
+        if (c < C && n < N) dst[(static_cast<size_t>(c) * T + t) * N + n] = f32_to_bf16(tile[tx][ty + 8 * i]);
+    }
+}
+
+PDT_API int pdt_transpose_w(const float* src, void* dst, int N, int T, int C, void* stream) {
+    if (N <= 0 || T <= 0 || C <= 0 || T > 65535) return -1;
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(pdt_cdiv(C, 32), pdt_cdiv(N, 32), T), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, static_cast<bf16*>(dst), N, T, C);
+    return pdt_launch_status();
+}

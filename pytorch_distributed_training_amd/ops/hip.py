@@ -1,0 +1,776 @@
+"""GPU implementations of the fused operators: ctypes bindings to ``libpdt_kernels.so`` and the
+``autograd.Function`` wrappers that give them backward passes.
+
+Conventions
+-----------
+* Activations are bf16.  Image tensors are logical NCHW with channels_last strides, i.e. physical
+  NHWC - the layout every kernel indexes.  Matrices are row-major ``[rows, features]``.
+* Parameters stay fp32 ("master" weights).  Kernels read bf16 copies kept in :class:`ShadowCache`;
+  the fused optimizer refreshes those copies in the same launch that updates the masters.
+* Weight gradients are produced in fp32, in the parameter's own physical element order.
+* Every launcher returns a status; a non-zero status raises.  Nothing here falls back to PyTorch ops.
+
+Role parity: the ATen/cuDNN/cuBLAS kernels implicitly launched by
+/root/reference/src/main.py:74-79.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import native
+
+_lib = native.kernels()
+_vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+_ip = ctypes.POINTER(ctypes.c_int)
+
+STAT_SLOTS = 32
+
+
+def _sig(name: str, argtypes):
+    fn = getattr(_lib, name)
+    fn.argtypes = argtypes
+    fn.restype = ctypes.c_int
+    return fn
+
+
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _vp])
+_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _vp])
+_bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
+_bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
+_bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp])
+_bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp])
+_bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp])
+_bn_relu_maxpool_fwd = _sig("pdt_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
+_maxpool_bn_bwd_reduce = _sig("pdt_maxpool_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
+_avgpool_fwd = _sig("pdt_avgpool_fwd", [_vp, _vp, _i, _i, _i, _vp])
+_avgpool_bwd = _sig("pdt_avgpool_bwd", [_vp, _vp, _i, _i, _i, _vp])
+_ce_fwd = _sig("pdt_softmax_ce_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp])
+_ce_bwd = _sig("pdt_softmax_ce_bwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _vp])
+_nchw_to_nhwc = _sig("pdt_nchw_to_nhwc_bf16", [_vp, _vp, _i, _i, _i, _i, _i, _vp])
+_im2col = _sig("pdt_im2col", [_vp, _vp] + [_i] * 9 + [_vp])
+_cast_pad = _sig("pdt_cast_pad_f32_bf16", [_vp, _vp, _ll, _i, _i, _vp])
+_transpose_w = _sig("pdt_transpose_w", [_vp, _vp, _i, _i, _i, _vp])
+_mt_step = _sig("pdt_multi_tensor_step", [_vp, _vp, _i, _i] + [_f] * 9 + [_i, _vp])
+_lib.pdt_opt_chunk_elems.restype = ctypes.c_int
+_lib.pdt_opt_desc_bytes.restype = ctypes.c_int
+_lib.pdt_opt_chunk_bytes.restype = ctypes.c_int
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def _check(rc: int, name: str) -> None:
+    if rc != 0:
+        why = "invalid arguments" if rc == -1 else f"hipError {rc}"
+        raise KernelError(f"{name}: {why}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _int_array(vals: Sequence[int]):
+    return (ctypes.c_int * max(len(vals), 1))(*vals)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------
+def _as_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """bf16, logical NCHW, physically NHWC-contiguous."""
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D image tensor, got shape {tuple(x.shape)}")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    n, c, h, w = x.shape
+    if x.stride() != (h * w * c, 1, w * c, c):  # size-1 dims make channels_last strides ambiguous
+        x = torch.as_strided(x, x.shape, (h * w * c, 1, w * c, c), x.storage_offset())
+    return x
+
+
+def _empty_nhwc(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
+    return torch.empty((n, h, w, c), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)
+
+
+def _check_size(t: torch.Tensor) -> None:
+    if t.numel() >= 2 ** 31:
+        raise ValueError("tensor too large for 32-bit element offsets")
+
+
+def to_device_layout(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    if dtype != torch.bfloat16:
+        raise ValueError("GPU kernels compute in bf16")
+    if x.dim() != 4:
+        return x.to(dtype)
+    if x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous():
+        x = x.to(torch.float32).contiguous()
+    n, c, h, w = x.shape
+    out = _empty_nhwc(n, c, h, w, x.device)
+    _check(_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), n, c, h, w, 0 if x.dtype == torch.float32 else 1, _stream()),
+           "nchw_to_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 weight copies
+# ------------------------------------------------------------------------------------------------
+class _Shadow:
+    __slots__ = ("ref", "version", "ptr", "fwd", "fwd_cols", "dgrad", "dgrad_epoch", "fresh_epoch")
+
+
+class ShadowCache:
+    """bf16 copies of fp32 parameters, keyed by parameter identity.
+
+    ``fwd``   - same physical element order as the parameter ([Cout][taps][Cin] for conv weights),
+                optionally with zero-padded rows (the stem's K = 147 -> 192).
+    ``dgrad`` - transposed to [Cin][taps][Cout] (padded) for the data-gradient GEMM; rebuilt lazily
+                after every optimizer step.
+    """
+
+    def __init__(self):
+        self._entries: Dict[int, _Shadow] = {}
+        self.epoch = 0  # bumped by the fused optimizer after it rewrote parameters in place
+
+    def _entry(self, p: torch.Tensor) -> _Shadow:
+        e = self._entries.get(id(p))
+        if e is None or e.ref() is not p:
+            e = _Shadow()
+            e.ref = weakref.ref(p)
+            e.version = -1
+            e.ptr = 0
+            e.fwd = e.dgrad = None
+            e.fwd_cols = 0
+            e.dgrad_epoch = e.fresh_epoch = -1
+            self._entries[id(p)] = e
+        return e
+
+    @staticmethod
+    def physical_matrix(p: torch.Tensor) -> torch.Tensor:
+        """fp32 [rows, cols] view (or copy) of the parameter in its physical element order."""
+        d = p.detach()
+        if d.dim() == 4:
+            d = d.permute(0, 2, 3, 1)  # [N, R, S, C]
+            if not d.is_contiguous():
+                d = d.contiguous()
+            return d.reshape(d.shape[0], -1)
+        if d.dim() == 2:
+            return d if d.is_contiguous() else d.contiguous()
+        raise ValueError("weights must be 2-D or 4-D")
+
+    def fwd(self, p: torch.Tensor, pad_cols_to: int = 8) -> torch.Tensor:
+        e = self._entry(p)
+        stale = (
+            e.fwd is None
+            or e.version != p._version
+            or e.ptr != p.data_ptr()
+            or (e.fresh_epoch != self.epoch)
+        )
+        mat = None
+        if stale:
+            mat = self.physical_matrix(p)
+            cols = _round_up(mat.shape[1], pad_cols_to)
+            if e.fwd is None or e.fwd.shape != (mat.shape[0], cols):
+                e.fwd = torch.empty((mat.shape[0], cols), dtype=torch.bfloat16, device=p.device)
+            _check(_cast_pad(mat.data_ptr(), e.fwd.data_ptr(), mat.shape[0], mat.shape[1], cols, _stream()), "cast_pad")
+            e.version, e.ptr, e.fresh_epoch = p._version, p.data_ptr(), self.epoch
+        return e.fwd
+
+    def optimizer_target(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        """bf16 buffer the optimizer kernel may refresh in place (same element order, no padding)."""
+        e = self._entries.get(id(p))
+        if e is None or e.ref() is not p or e.fwd is None or e.fwd.numel() != p.numel():
+            return None
+        if p.dim() == 4 and not p.permute(0, 2, 3, 1).is_contiguous():
+            return None
+        if p.dim() != 4 and not p.is_contiguous():
+            return None
+        return e.fwd
+
+    def mark_refreshed(self, p: torch.Tensor) -> None:
+        e = self._entries.get(id(p))
+        if e is not None and e.ref() is p:
+            e.version, e.ptr, e.fresh_epoch = p._version, p.data_ptr(), self.epoch
+
+    def dgrad(self, p: torch.Tensor, taps: int) -> Tuple[torch.Tensor, int]:
+        """([Cin][taps][Npad] bf16, Npad) with Npad = Cout rounded up to 64."""
+        e = self._entry(p)
+        mat = self.physical_matrix(p)  # [N, taps*C]
+        n = mat.shape[0]
+        c = mat.shape[1] // taps
+        npad = _round_up(n, 64)
+        if e.dgrad is None or e.dgrad_epoch != self.epoch or e.version != p._version or e.dgrad.shape != (c, taps * npad):
+            if e.dgrad is None or e.dgrad.shape != (c, taps * npad):
+                e.dgrad = torch.zeros((c, taps * npad), dtype=torch.bfloat16, device=p.device)
+            if npad == n:
+                _check(_transpose_w(mat.data_ptr(), e.dgrad.data_ptr(), n, taps, c, _stream()), "transpose_w")
+            else:  # rows of the transposed matrix are longer than N: transpose per tap into strided slots
+                tmp = torch.empty((c, taps * n), dtype=torch.bfloat16, device=p.device)
+                _check(_transpose_w(mat.data_ptr(), tmp.data_ptr(), n, taps, c, _stream()), "transpose_w")
+                e.dgrad.view(c, taps, npad)[:, :, :n].copy_(tmp.view(c, taps, n))
+            e.dgrad_epoch = self.epoch
+            if e.fwd is None:
+                e.version = p._version
+        return e.dgrad, npad
+
+
+SHADOWS = ShadowCache()
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM / convolution launch helpers
+# ------------------------------------------------------------------------------------------------
+def _pick_tile(m: int, n: int) -> int:
+    if n <= 64:
+        return 1 if m >= 128 else 2
+    return 0
+
+
+def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
+                        oph, opw) -> None:
+    dh = _int_array([t[0] for t in taps])
+    dw = _int_array([t[1] for t in taps])
+    wo = _int_array([t[2] for t in taps])
+    _check(
+        _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), M, N, ldb, ldo, C, len(taps),
+                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), _stream()),
+        "gather_gemm",
+    )
+
+
+def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB) -> None:
+    tile = 0 if (N > 64 and C > 64) else 1
+    bt = 128 if tile == 0 else 64
+    tiles = math.ceil(N / bt) * math.ceil(C / bt) * len(taps)
+    splits = max(1, min(1024 // max(tiles, 1), M // 512))
+    dh = _int_array([t[0] for t in taps])
+    dwi = _int_array([t[1] for t in taps])
+    wo = _int_array([t[2] for t in taps])
+    _check(
+        _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
+               wo, splits, tile, _stream()),
+        "wgrad",
+    )
+
+
+def _conv_out(h: int, k: int, s: int, p: int) -> int:
+    return (h + 2 * p - k) // s + 1
+
+
+class _ConvStats(torch.autograd.Function):
+    """y = conv2d(x, w) (no bias) and per-channel statistic accumulators of y."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride: int, padding: int, want_stats: bool):
+        x = _as_nhwc(x)
+        nb, c, h, w_ = x.shape
+        n, c2, r, s = weight.shape
+        if c != c2:
+            raise ValueError(f"channel mismatch: input {c}, weight {c2}")
+        ho, wo = _conv_out(h, r, stride, padding), _conv_out(w_, s, stride, padding)
+        M = nb * ho * wo
+        _check_size(x)
+        if n % 8 != 0:
+            raise ValueError("output channels must be a multiple of 8")
+        y = _empty_nhwc(nb, n, ho, wo, x.device)
+        _check_size(y)
+        stats = torch.zeros((STAT_SLOTS, 2, n), dtype=torch.float32, device=x.device) if want_stats else None
+        ctx.geom = (nb, c, h, w_, n, r, s, ho, wo, stride, padding)
+        ctx.col = None
+        if c % 64 == 0:
+            wb = SHADOWS.fwd(weight)
+            taps = [(i - padding, j - padding, (i * s + j) * c) for i in range(r) for j in range(s)]
+            _launch_gather_gemm(x, wb, y, stats, None, M, n, r * s * c, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0)
+            ctx.save_for_backward(x, weight)
+        else:
+            # few input channels (the stem): explicit patch matrix, then a plain GEMM
+            k = r * s * c
+            kpad = _round_up(k, 64)
+            col = torch.empty((M, kpad), dtype=torch.bfloat16, device=x.device)
+            _check_size(col)
+            _check(_im2col(x.data_ptr(), col.data_ptr(), nb, h, w_, c, r, s, stride, padding, kpad, _stream()), "im2col")
+            wb = SHADOWS.fwd(weight, pad_cols_to=64)
+            _launch_gather_gemm(col, wb, y, stats, None, M, n, kpad, n, kpad, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+            ctx.save_for_backward(col, weight)
+            ctx.col = kpad
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        saved, weight = ctx.saved_tensors
+        nb, c, h, w_, n, r, s, ho, wo, stride, padding = ctx.geom
+        dy = _as_nhwc(dy)
+        M = nb * ho * wo
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.col is None:
+                dwp = torch.zeros((n, r, s, c), dtype=torch.float32, device=dy.device)
+                taps = [(i - padding, j - padding, (i * s + j) * c) for i in range(r) for j in range(s)]
+                _launch_wgrad(dy, saved, dwp, M, n, n, c, taps, r * s * c, h, w_, stride, ho, wo)
+                dw = dwp.permute(0, 3, 1, 2)
+            else:
+                kpad = ctx.col
+                dwp = torch.zeros((n, kpad), dtype=torch.float32, device=dy.device)
+                _launch_wgrad(dy, saved, dwp, M, n, n, kpad, [(0, 0, 0)], kpad, 1, 1, 1, 1, 1)
+                dw = dwp[:, : r * s * c].reshape(n, r, s, c).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[0]:
+            if ctx.col is not None:
+                raise NotImplementedError("data gradient of a convolution with Cin % 64 != 0")
+            wt, npad = SHADOWS.dgrad(weight, r * s)
+            if npad != n:
+                raise NotImplementedError("data gradient needs Cout % 64 == 0")
+            dx = _empty_nhwc(nb, c, h, w_, dy.device)
+            for ph in range(stride):
+                oa = (h - ph + stride - 1) // stride
+                if oa <= 0:
+                    continue
+                for pw in range(stride):
+                    ob = (w_ - pw + stride - 1) // stride
+                    if ob <= 0:
+                        continue
+                    taps = []
+                    for i in range(r):
+                        if (ph + padding - i) % stride != 0:
+                            continue
+                        for j in range(s):
+                            if (pw + padding - j) % stride != 0:
+                                continue
+                            taps.append(((ph + padding - i) // stride, (pw + padding - j) // stride, (i * s + j) * npad))
+                    _launch_gather_gemm(dy, wt, dx, None, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
+                                        oa, ob, h, w_, stride, ph, pw)
+        return dx, dw, None, None, None
+
+
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0):
+    return _ConvStats.apply(x, weight, stride, padding, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm family
+# ------------------------------------------------------------------------------------------------
+def _bn_consts(stats: Optional[torch.Tensor], bn: nn.BatchNorm2d, count: int, device) -> torch.Tensor:
+    """[4, C] fp32: mean, rstd, scale, shift.  Training mode also updates the running statistics."""
+    c = bn.num_features
+    consts = torch.empty((4, c), dtype=torch.float32, device=device)
+    training = bn.training or not bn.track_running_stats
+    if training and stats is None:
+        raise ValueError("training-mode BatchNorm needs the statistics produced by the convolution")
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats and bn.running_mean is not None
+    _check(
+        _bn_finalize(_ptr(stats), c, float(count), _ptr(bn.weight), _ptr(bn.bias),
+                     _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                     _ptr(bn.num_batches_tracked) if (track and training) else None, momentum, bn.eps,
+                     1 if training else 0, consts.data_ptr(), _stream()),
+        "bn_finalize",
+    )
+    return consts
+
+
+def _bn_backward(dout, out, y, consts, gamma, count, c, y2=None, consts2=None, gamma2=None, want_dz=False):
+    """Shared backward: returns (dy, dgamma, dbeta, extra) where extra = dz | (dy2, dgamma2, dbeta2) | None."""
+    dev = y.device
+    M = y.numel() // c
+    slots = torch.zeros((STAT_SLOTS, 3, c), dtype=torch.float32, device=dev)
+    _check(_bn_bwd_reduce(dout.data_ptr(), _ptr(out), y.data_ptr(), consts.data_ptr(), _ptr(y2), _ptr(consts2),
+                          slots.data_ptr(), M, c, _stream()), "bn_bwd_reduce")
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+    _check(_bn_bwd_finalize(slots.data_ptr(), c, 1, float(count), _ptr(gamma), consts.data_ptr(), dgamma.data_ptr(),
+                            dbeta.data_ptr(), coef.data_ptr(), _stream()), "bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    extra = None
+    dz = dy2 = coef2 = None
+    if y2 is not None:
+        dgamma2 = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta2 = torch.empty(c, dtype=torch.float32, device=dev)
+        coef2 = torch.empty((3, c), dtype=torch.float32, device=dev)
+        _check(_bn_bwd_finalize(slots.data_ptr(), c, 2, float(count), _ptr(gamma2), consts2.data_ptr(),
+                                dgamma2.data_ptr(), dbeta2.data_ptr(), coef2.data_ptr(), _stream()), "bn_bwd_finalize")
+        dy2 = torch.empty_like(y2)
+        extra = (dy2, dgamma2, dbeta2)
+    elif want_dz:
+        dz = torch.empty_like(y)
+        extra = dz
+    _check(_bn_bwd_apply(dout.data_ptr(), _ptr(out), y.data_ptr(), coef.data_ptr(), dy.data_ptr(), _ptr(dz), _ptr(y2),
+                         _ptr(coef2), _ptr(dy2), y.numel(), c, _stream()), "bn_bwd_apply")
+    return dy, dgamma, dbeta, extra
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, bn, relu: bool):
+        y = _as_nhwc(y)
+        nb, c, h, w = y.shape
+        count = nb * h * w
+        consts = _bn_consts(stats, bn, count, y.device)
+        out = torch.empty_like(y)
+        _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), None, None, out.data_ptr(), y.numel(), c, int(relu),
+                             _stream()), "bn_apply_fwd")
+        ctx.save_for_backward(y, out if relu else None, consts, gamma)
+        ctx.meta = (count, c, relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, consts, gamma = ctx.saved_tensors
+        count, c, relu = ctx.meta
+        dout = _as_nhwc(dout)
+        dy, dgamma, dbeta, _ = _bn_backward(dout, out, y, consts, gamma, count, c)
+        return dy, None, dgamma, dbeta, None, None
+
+
+class _BnAddRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, bn, ident, id_stats, id_gamma, id_beta, id_bn):
+        y = _as_nhwc(y)
+        ident = _as_nhwc(ident)
+        if ident.shape != y.shape:
+            raise ValueError(f"shortcut shape {tuple(ident.shape)} != {tuple(y.shape)}")
+        nb, c, h, w = y.shape
+        count = nb * h * w
+        consts = _bn_consts(stats, bn, count, y.device)
+        iconsts = _bn_consts(id_stats, id_bn, count, y.device) if id_bn is not None else None
+        out = torch.empty_like(y)
+        _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), ident.data_ptr(), _ptr(iconsts), out.data_ptr(), y.numel(),
+                             c, 1, _stream()), "bn_apply_fwd")
+        ctx.projected = id_bn is not None
+        ctx.save_for_backward(y, out, consts, gamma, ident if ctx.projected else None, iconsts, id_gamma)
+        ctx.meta = (count, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, consts, gamma, ident, iconsts, id_gamma = ctx.saved_tensors
+        count, c = ctx.meta
+        dout = _as_nhwc(dout)
+        if ctx.projected:
+            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, out, y, consts, gamma, count, c, ident,
+                                                                      iconsts, id_gamma)
+            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None
+        dy, dgamma, dbeta, dz = _bn_backward(dout, out, y, consts, gamma, count, c, want_dz=True)
+        return dy, None, dgamma, dbeta, None, dz, None, None, None, None
+
+
+class _BnReluMaxpool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, bn):
+        y = _as_nhwc(y)
+        nb, c, h, w = y.shape
+        count = nb * h * w
+        consts = _bn_consts(stats, bn, count, y.device)
+        ho, wo = _conv_out(h, 3, 2, 1), _conv_out(w, 3, 2, 1)
+        out = _empty_nhwc(nb, c, ho, wo, y.device)
+        idx = torch.empty((nb, ho, wo, c), dtype=torch.uint8, device=y.device)
+        _check(_bn_relu_maxpool_fwd(y.data_ptr(), consts.data_ptr(), out.data_ptr(), idx.data_ptr(), nb, h, w, c,
+                                    _stream()), "bn_relu_maxpool_fwd")
+        ctx.save_for_backward(y, idx, consts, gamma)
+        ctx.meta = (count, c, nb, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, idx, consts, gamma = ctx.saved_tensors
+        count, c, nb, h, w = ctx.meta
+        dout = _as_nhwc(dout)
+        dev = y.device
+        dz = torch.empty_like(y)
+        slots = torch.zeros((STAT_SLOTS, 3, c), dtype=torch.float32, device=dev)
+        _check(_maxpool_bn_bwd_reduce(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), dz.data_ptr(),
+                                      slots.data_ptr(), nb, h, w, c, _stream()), "maxpool_bn_bwd_reduce")
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+        _check(_bn_bwd_finalize(slots.data_ptr(), c, 1, float(count), _ptr(gamma), consts.data_ptr(), dgamma.data_ptr(),
+                                dbeta.data_ptr(), coef.data_ptr(), _stream()), "bn_bwd_finalize")
+        dy = torch.empty_like(y)
+        _check(_bn_bwd_apply(dz.data_ptr(), None, y.data_ptr(), coef.data_ptr(), dy.data_ptr(), None, None, None, None,
+                             y.numel(), c, _stream()), "bn_bwd_apply")
+        return dy, None, dgamma, dbeta, None
+
+
+def bn_act(y, stats, bn, relu: bool = True):
+    return _BnAct.apply(y, stats, bn.weight, bn.bias, bn, relu)
+
+
+def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
+    a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True)
+    return _ConvStats.apply(a, weight, stride, padding, True)
+
+
+def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
+    if id_bn is not None:
+        return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn)
+    return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None)
+
+
+def bn_relu_maxpool(y, stats, bn):
+    return _BnReluMaxpool.apply(y, stats, bn.weight, bn.bias, bn)
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        a = _as_nhwc(a)
+        nb, c, h, w = a.shape
+        out = torch.empty((nb, c), dtype=torch.bfloat16, device=a.device)
+        _check(_avgpool_fwd(a.data_ptr(), out.data_ptr(), nb, h * w, c, _stream()), "avgpool_fwd")
+        ctx.meta = (nb, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nb, c, h, w = ctx.meta
+        g = g.to(torch.bfloat16).contiguous()
+        da = _empty_nhwc(nb, c, h, w, g.device)
+        _check(_avgpool_bwd(g.data_ptr(), da.data_ptr(), nb, h * w, c, _stream()), "avgpool_bwd")
+        return da
+
+
+def global_avgpool(a):
+    return _GlobalAvgPool.apply(a)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear
+# ------------------------------------------------------------------------------------------------
+_PADDED_GRADS: Dict[int, int] = {}  # data_ptr of a zero-padded gradient buffer -> its row stride
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, k = weight.shape
+        if k % 64 != 0:
+            raise ValueError("in_features must be a multiple of 64")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, k)
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        npad = n if n % 64 == 0 else _round_up(n, 64)
+        out = torch.empty((M, npad), dtype=torch.bfloat16, device=x.device)
+        _check_size(out)
+        _check_size(x2)
+        wb = SHADOWS.fwd(weight)
+        bias_f = bias.detach() if bias is not None else None
+        _launch_gather_gemm(x2, wb, out, None, bias_f, M, n, k, npad, k, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+        ctx.save_for_backward(x2, weight)
+        ctx.meta = (lead, n, k, npad, bias is not None)
+        res = out[:, :n] if npad != n else out
+        return res.reshape(*lead, n) if len(lead) != 1 else res
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, weight = ctx.saved_tensors
+        lead, n, k, npad, has_bias = ctx.meta
+        M = x2.shape[0]
+        g2 = g.reshape(M, n)
+        if g2.dtype != torch.bfloat16:
+            g2 = g2.to(torch.bfloat16)
+        if npad == n:
+            gp = g2 if g2.is_contiguous() else g2.contiguous()
+        elif _PADDED_GRADS.pop(g2.data_ptr(), None) == npad and g2.stride() == (npad, 1):
+            gp = torch.as_strided(g2, (M, npad), (npad, 1))  # produced zero-padded by the loss kernel
+        else:
+            gp = torch.zeros((M, npad), dtype=torch.bfloat16, device=g.device)
+            gp[:, :n].copy_(g2)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt, npad_w = SHADOWS.dgrad(weight, 1)  # [k][npad]
+            assert npad_w == npad
+            dx = torch.empty((M, k), dtype=torch.bfloat16, device=g.device)
+            _launch_gather_gemm(gp, wt, dx, None, None, M, k, npad, k, npad, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+            dx = dx.reshape(*lead, k)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((n, k), dtype=torch.float32, device=g.device)
+            _launch_wgrad(gp, x2, dw, M, n, npad, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = gp[:, :n].sum(dim=0, dtype=torch.float32)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None, activation: Optional[str] = None):
+    out = _Linear.apply(x, weight, bias)
+    if activation == "gelu":
+        return gelu(out)
+    if activation == "relu":
+        return torch.relu(out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Softmax cross-entropy
+# ------------------------------------------------------------------------------------------------
+class _SoftmaxCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            logits = logits.reshape(-1, logits.shape[-1]).contiguous()
+        if logits.dtype not in (torch.bfloat16, torch.float32):
+            logits = logits.float()
+        rows, classes = logits.shape
+        labels = labels.reshape(-1).to(torch.int64).contiguous()
+        if labels.numel() != rows:
+            raise ValueError("labels and logits disagree on the number of rows")
+        dev = logits.device
+        row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dt = 1 if logits.dtype == torch.bfloat16 else 0
+        _check(_ce_fwd(logits.data_ptr(), labels.data_ptr(), row_loss.data_ptr(), lse.data_ptr(), loss.data_ptr(), rows,
+                       classes, logits.stride(0), dt, _stream()), "softmax_ce_fwd")
+        ctx.save_for_backward(logits, labels, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse = ctx.saved_tensors
+        rows, classes = logits.shape
+        ld = logits.stride(0)
+        pad_to = ld if ld >= classes and ld - classes < 64 else classes
+        dbuf = torch.empty((rows, pad_to), dtype=logits.dtype, device=logits.device)
+        g1 = g.reshape(1).to(torch.float32).contiguous()
+        dt = 1 if logits.dtype == torch.bfloat16 else 0
+        _check(_ce_bwd(logits.data_ptr(), labels.data_ptr(), lse.data_ptr(), g1.data_ptr(), dbuf.data_ptr(), rows, classes,
+                       ld, pad_to, pad_to, dt, _stream()), "softmax_ce_bwd")
+        if pad_to != classes:
+            _PADDED_GRADS[dbuf.data_ptr()] = pad_to
+            return dbuf[:, :classes], None
+        return dbuf, None
+
+
+def softmax_cross_entropy(logits, labels):
+    return _SoftmaxCE.apply(logits, labels)
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-tensor optimizer step
+# ------------------------------------------------------------------------------------------------
+class MultiTensorPlan:
+    """Device-resident descriptor and chunk tables for one parameter group."""
+
+    def __init__(self, params: List[torch.Tensor], states: List[List[torch.Tensor]]):
+        import numpy as np
+
+        self.keys = [(p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for p in params]
+        self.params = params
+        dev = params[0].device
+        chunk = _lib.pdt_opt_chunk_elems()
+        assert _lib.pdt_opt_desc_bytes() == 48 and _lib.pdt_opt_chunk_bytes() == 16
+        desc = np.zeros((len(params), 6), dtype=np.int64)
+        chunks = []
+        self.shadow_params = []
+        for i, (p, st) in enumerate(zip(params, states)):
+            if p.dtype != torch.float32 or p.grad is None or p.grad.dtype != torch.float32:
+                raise TypeError("fused optimizer needs fp32 parameters and gradients")
+            if not _same_dense_layout(p, p.grad) or any(not _same_dense_layout(p, s) for s in st):
+                raise ValueError("parameter, gradient and state must share one dense layout")
+            shadow = SHADOWS.optimizer_target(p)
+            if shadow is not None:
+                self.shadow_params.append(p)
+            desc[i] = [p.data_ptr(), p.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr() if len(st) > 1 else 0,
+                       shadow.data_ptr() if shadow is not None else 0, p.numel()]
+            for start in range(0, p.numel(), chunk):
+                chunks.append((i, 0, start))
+        ch = np.zeros((len(chunks), 2), dtype=np.int64)
+        for j, (t, _pad, start) in enumerate(chunks):
+            ch[j, 0] = t  # int32 tensor index + int32 padding (little endian)
+            ch[j, 1] = start
+        self.n_chunks = len(chunks)
+        self.desc = torch.from_numpy(desc).to(dev)
+        self.chunks = torch.from_numpy(ch).to(dev)
+
+    def matches(self, params: List[torch.Tensor]) -> bool:
+        if len(params) != len(self.keys):
+            return False
+        for p, (pp, gp) in zip(params, self.keys):
+            if p.data_ptr() != pp or p.grad is None or p.grad.data_ptr() != gp:
+                return False
+        return all(SHADOWS.optimizer_target(p) is not None for p in self.shadow_params)
+
+
+def _same_dense_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a.shape == b.shape and a.stride() == b.stride() and a.numel() * a.element_size() == _span_bytes(a)
+
+
+def _span_bytes(t: torch.Tensor) -> int:
+    if t.numel() == 0:
+        return 0
+    return (sum((s - 1) * st for s, st in zip(t.shape, t.stride())) + 1) * t.element_size()
+
+
+_MODE = {"adam": 0, "adamw": 1, "sgd": 2}
+
+
+def multi_tensor_step(plan: MultiTensorPlan, group) -> None:
+    t = group["step"]
+    b1, b2 = group["betas"]
+    bc1 = 1.0 - b1 ** t
+    bc2s = math.sqrt(1.0 - b2 ** t)
+    _check(
+        _mt_step(plan.desc.data_ptr(), plan.chunks.data_ptr(), plan.n_chunks, _MODE[group["mode"]], group["lr"], b1, b2,
+                 group["eps"], group["weight_decay"], bc1, bc2s, group["momentum"], group["grad_scale"],
+                 1 if t == 1 else 0, _stream()),
+        "multi_tensor_step",
+    )
+    SHADOWS.epoch += 1
+    for p in plan.shadow_params:
+        SHADOWS.mark_refreshed(p)
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer operators (LayerNorm, GELU, attention, embedding, bias+residual)
+# ------------------------------------------------------------------------------------------------
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    from . import hip_transformer as ht
+
+    return ht.layer_norm(x, weight, bias, eps)
+
+
+def gelu(x):
+    from . import hip_transformer as ht
+
+    return ht.gelu(x)
+
+
+def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
+    from . import hip_transformer as ht
+
+    return ht.attention(q, k, v, causal, scale)
+
+
+def embedding(ids, weight):
+    from . import hip_transformer as ht
+
+    return ht.embedding(ids, weight)
+
+
+def add_bias_residual(x, bias, residual):
+    from . import hip_transformer as ht
+
+    return ht.add_bias_residual(x, bias, residual)

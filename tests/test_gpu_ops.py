@@ -1,0 +1,288 @@
+"""Numerics of the HIP kernels against plain PyTorch fp32 references (needs an MI355X)."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pytorch_distributed_training_amd.ops import hip as h
+
+    return h
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _rel_err(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+CONV_CASES = [
+    # (batch, cin, cout, k, stride, pad, hw)
+    (8, 64, 64, 1, 1, 0, 56),
+    (8, 64, 64, 3, 1, 1, 56),
+    (8, 64, 256, 1, 1, 0, 56),
+    (8, 256, 64, 1, 1, 0, 56),
+    (4, 128, 128, 3, 2, 1, 56),
+    (4, 256, 512, 1, 2, 0, 56),
+    (8, 256, 256, 3, 1, 1, 14),
+    (8, 512, 512, 3, 1, 1, 7),
+    (3, 1024, 2048, 1, 2, 0, 14),
+    (5, 64, 128, 3, 2, 1, 15),  # odd sizes: edge tiles, partial parity classes
+    (2, 3, 64, 7, 2, 3, 64),    # stem (patch-matrix path)
+]
+
+
+@pytest.mark.parametrize("nb,cin,cout,k,stride,pad,hw", CONV_CASES)
+def test_conv_forward_backward(hip, nb, cin, cout, k, stride, pad, hw):
+    torch.manual_seed(0)
+    dev = _dev()
+    x = torch.randn(nb, cin, hw, hw, device=dev)
+    w = (torch.randn(cout, cin, k, k, device=dev) / math.sqrt(cin * k * k)).contiguous(memory_format=torch.channels_last)
+    w = nn.Parameter(w)
+    xb = hip.to_device_layout(x).requires_grad_(cin % 64 == 0)
+    y, stats = hip.conv2d_stats(xb, w, stride, pad)
+    # reference: same bf16-rounded operands, fp32 math
+    xr = _bf16_round(x).requires_grad_(True)
+    wr = _bf16_round(w.detach()).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16
+    assert _rel_err(y, yr) < 6e-3
+    s = stats.sum(dim=0)
+    yf = y.float()
+    assert torch.allclose(s[0], yf.sum(dim=(0, 2, 3)), rtol=2e-3, atol=2e-2 * math.sqrt(yf[:, 0].numel()))
+    assert torch.allclose(s[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=2e-3, atol=1e-2)
+    g = torch.randn_like(yr)
+    gb = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(gb)
+    yr.backward(_bf16_round(g))
+    assert _rel_err(w.grad, wr.grad) < 8e-3
+    if cin % 64 == 0:
+        assert _rel_err(xb.grad, xr.grad) < 8e-3
+
+
+@pytest.mark.parametrize("m,k,n,bias", [(256, 2048, 1000, True), (64, 512, 10, True), (300, 768, 3072, False), (197 * 4, 768, 768, True)])
+def test_linear_forward_backward(hip, m, k, n, bias):
+    torch.manual_seed(1)
+    dev = _dev()
+    x = torch.randn(m, k, device=dev)
+    lin = nn.Linear(k, n, bias=bias).to(dev)
+    xb = x.to(torch.bfloat16).requires_grad_(True)
+    out = hip.linear(xb, lin.weight, lin.bias)
+    xr = _bf16_round(x).requires_grad_(True)
+    wr = _bf16_round(lin.weight.detach()).requires_grad_(True)
+    br = lin.bias.detach().clone().requires_grad_(True) if bias else None
+    ref = F.linear(xr, wr, br)
+    assert out.shape == ref.shape
+    assert _rel_err(out, ref) < 6e-3
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(_bf16_round(g))
+    assert _rel_err(xb.grad, xr.grad) < 8e-3
+    assert _rel_err(lin.weight.grad, wr.grad) < 8e-3
+    if bias:
+        assert _rel_err(lin.bias.grad, br.grad) < 8e-3
+
+
+def _ref_bn(y, bn):
+    return F.batch_norm(y, None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+
+
+@pytest.mark.parametrize("nb,c,hw", [(8, 64, 56), (4, 256, 14), (6, 2048, 7)])
+@pytest.mark.parametrize("variant", ["act", "add", "proj"])
+def test_bn_family_forward_backward(hip, nb, c, hw, variant):
+    torch.manual_seed(2)
+    dev = _dev()
+    conv = nn.Conv2d(64, c, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    x = hip.to_device_layout(torch.randn(nb, 64, hw, hw, device=dev))
+    bn = nn.BatchNorm2d(c).to(dev)
+    bn2 = nn.BatchNorm2d(c).to(dev)
+    with torch.no_grad():
+        for b in (bn, bn2):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.uniform_(-0.5, 0.5)
+    y, st = hip.conv2d_stats(x, conv.weight, 1, 0)
+    y = y.detach().requires_grad_(True)
+    ident = hip.to_device_layout(torch.randn(nb, c, hw, hw, device=dev)).requires_grad_(True)
+    yr = y.detach().float().requires_grad_(True)
+    ir = ident.detach().float().requires_grad_(True)
+    rbn = nn.BatchNorm2d(c).to(dev)
+    rbn2 = nn.BatchNorm2d(c).to(dev)
+    rbn.load_state_dict(bn.state_dict())
+    rbn2.load_state_dict(bn2.state_dict())
+    if variant == "act":
+        out = hip.bn_act(y, st, bn, True)
+        ref = F.relu(_ref_bn(yr, rbn))
+    elif variant == "add":
+        out = hip.bn_add_relu(y, st, bn, ident)
+        ref = F.relu(_ref_bn(yr, rbn) + ir)
+    else:
+        # the shortcut statistics are those of `ident` itself
+        ist = torch.zeros_like(st)
+        idf = ident.detach().float()
+        ist[0, 0] = idf.sum(dim=(0, 2, 3))
+        ist[0, 1] = (idf * idf).sum(dim=(0, 2, 3))
+        out = hip.bn_add_relu(y, st, bn, ident, ist, bn2)
+        ref = F.relu(_ref_bn(yr, rbn) + _ref_bn(ir, rbn2))
+    assert _rel_err(out, ref) < 1e-2
+    # running statistics were updated with momentum 0.1 and the unbiased variance
+    m = yr.detach().mean(dim=(0, 2, 3))
+    v = yr.detach().var(dim=(0, 2, 3), unbiased=True)
+    assert torch.allclose(bn.running_mean, 0.1 * m, atol=2e-3, rtol=1e-2)
+    assert torch.allclose(bn.running_var, 0.9 + 0.1 * v, atol=2e-3, rtol=1e-2)
+    assert int(bn.num_batches_tracked) == 1
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    ref.backward(_bf16_round(g))
+    assert _rel_err(y.grad, yr.grad) < 2e-2
+    assert _rel_err(bn.weight.grad, rbn.weight.grad) < 2e-2
+    assert _rel_err(bn.bias.grad, rbn.bias.grad) < 2e-2
+    if variant == "add":
+        assert _rel_err(ident.grad, ir.grad) < 1e-2
+    if variant == "proj":
+        assert _rel_err(ident.grad, ir.grad) < 2e-2
+        assert _rel_err(bn2.weight.grad, rbn2.weight.grad) < 2e-2
+
+
+def test_bn_eval_uses_running_stats(hip):
+    dev = _dev()
+    bn = nn.BatchNorm2d(64).to(dev).eval()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    y = hip.to_device_layout(torch.randn(4, 64, 8, 8, device=dev))
+    out = hip.bn_act(y, None, bn, True)
+    ref = F.relu(bn(y.float()))
+    assert _rel_err(out, ref) < 1e-2
+
+
+def test_stem_tail_maxpool(hip):
+    torch.manual_seed(3)
+    dev = _dev()
+    conv = nn.Conv2d(64, 64, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    x = hip.to_device_layout(torch.randn(4, 64, 30, 30, device=dev))
+    bn = nn.BatchNorm2d(64).to(dev)
+    y, st = hip.conv2d_stats(x, conv.weight, 1, 0)
+    y = y.detach().requires_grad_(True)
+    out = hip.bn_relu_maxpool(y, st, bn)
+    yr = y.detach().float().requires_grad_(True)
+    rbn = nn.BatchNorm2d(64).to(dev)
+    ref = F.max_pool2d(F.relu(_ref_bn(yr, rbn)), 3, 2, 1)
+    assert out.shape == ref.shape
+    assert _rel_err(out, ref) < 1e-2
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    ref.backward(_bf16_round(g))
+    assert _rel_err(y.grad, yr.grad) < 3e-2
+
+
+def test_global_avgpool(hip):
+    dev = _dev()
+    a = hip.to_device_layout(torch.randn(6, 128, 7, 7, device=dev)).requires_grad_(True)
+    out = hip.global_avgpool(a)
+    ref = a.detach().float().mean(dim=(2, 3))
+    assert _rel_err(out, ref) < 5e-3
+    out.backward(torch.ones_like(out))
+    assert torch.allclose(a.grad.float(), torch.full_like(a.grad.float(), 1 / 49), rtol=1e-2)
+
+
+@pytest.mark.parametrize("rows,classes,dtype", [(256, 1000, torch.bfloat16), (32, 10, torch.float32), (64, 50257, torch.bfloat16)])
+def test_softmax_cross_entropy(hip, rows, classes, dtype):
+    torch.manual_seed(4)
+    dev = _dev()
+    logits = (3 * torch.randn(rows, classes, device=dev)).to(dtype).requires_grad_(True)
+    labels = torch.randint(0, classes, (rows,), device=dev)
+    loss = hip.softmax_cross_entropy(logits, labels)
+    lr = logits.detach().float().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels)
+    assert abs(float(loss) - float(ref)) < 2e-3 * max(1.0, abs(float(ref)))
+    (2.0 * loss).backward()
+    (2.0 * ref).backward()
+    assert _rel_err(logits.grad, lr.grad) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["adam", "adamw", "sgd"])
+def test_multi_tensor_optimizer_matches_cpu_definition(mode):
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    torch.manual_seed(5)
+    dev = _dev()
+    shapes = [(64, 3, 7, 7), (1000, 2048), (2048,), (33,), (5, 7)]
+    cpu = [nn.Parameter(torch.randn(s)) for s in shapes]
+    gpu = [nn.Parameter(p.detach().to(dev)) for p in cpu]
+    kw = dict(mode=mode, lr=0.01, weight_decay=0.05, momentum=0.9)
+    oc, og = FusedOptimizer(cpu, **kw), FusedOptimizer(gpu, **kw)
+    for _ in range(3):
+        for pc, pg in zip(cpu, gpu):
+            g = torch.randn_like(pc)
+            pc.grad = g.clone()
+            pg.grad = g.to(dev)
+        oc.step()
+        og.step()
+    for pc, pg in zip(cpu, gpu):
+        assert torch.allclose(pg.detach().cpu(), pc.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_optimizer_refreshes_bf16_weight_copies(hip):
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    dev = _dev()
+    lin = nn.Linear(64, 64, bias=False).to(dev)
+    x = torch.randn(8, 64, device=dev).to(torch.bfloat16)
+    opt = FusedOptimizer(lin.parameters(), mode="sgd", lr=0.5, momentum=0.0, weight_decay=0.0)
+    hip.linear(x, lin.weight).float().pow(2).sum().backward()
+    opt.step()
+    shadow = hip.SHADOWS.fwd(lin.weight)
+    assert torch.equal(shadow, lin.weight.detach().to(torch.bfloat16))
+    out = hip.linear(x, lin.weight)
+    assert _rel_err(out, F.linear(x.float(), _bf16_round(lin.weight.detach()))) < 6e-3
+
+
+def test_resnet18_matches_reference_model_and_learns():
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    torch.manual_seed(6)
+    dev = _dev()
+    ref = build_model("resnet18", num_classes=10)
+    gpu = build_model("resnet18", num_classes=10)
+    gpu.load_state_dict(ref.state_dict())
+    gpu = gpu.to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(16, 3, 64, 64)
+    y = torch.randint(0, 10, (16,))
+    ref_logits = ref(x)
+    ref_loss = F.cross_entropy(ref_logits, y)
+    ref_loss.backward()
+    xb = ops.to_device_layout(x.to(dev))
+    logits = gpu(xb)
+    loss = ops.softmax_cross_entropy(logits, y.to(dev))
+    loss.backward()
+    assert _rel_err(logits.detach().cpu(), ref_logits.detach()) < 0.08
+    assert abs(float(loss) - float(ref_loss)) < 0.08
+    gr = dict(ref.named_parameters())
+    for name, p in gpu.named_parameters():
+        assert p.grad is not None, name
+        assert p.grad.shape == p.shape
+    assert _rel_err(gpu.fc.weight.grad.cpu(), gr["fc.weight"].grad) < 0.1
+    assert _rel_err(gpu.conv1.weight.grad.cpu(), gr["conv1.weight"].grad) < 0.25
+    opt = FusedOptimizer(gpu.parameters(), mode="adam", lr=1e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        l = ops.softmax_cross_entropy(gpu(xb), y.to(dev))
+        l.backward()
+        opt.step()
+        losses.append(float(l))
+    assert losses[-1] < 0.6 * losses[0]
