@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (exhaustive MIOpen search; slow start)")
     args = ap.parse_args()
 
     from pytorch_distributed_training_amd import ops
@@ -42,7 +43,7 @@ def main():
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     model = build_model(args.model, 1000, args.image_size).to(dev).to(memory_format=torch.channels_last)
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     xs = [torch.randn(args.batch_size, 3, args.image_size, args.image_size, device=dev).contiguous(
@@ -59,6 +60,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+        torch.cuda.synchronize()
+        print(f"warmup step {i} done at {time.perf_counter():.1f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):

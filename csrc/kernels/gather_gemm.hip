@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
                       int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
                       int splits, int tile, void* stream) {
-    if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (C % 8) != 0 || (N % 8) != 0 || (ldy % 8) != 0)
+    // rows of dY are read in 8-column chunks: ldy must cover N rounded up to 8 (columns >= N are ignored)
+    if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (C % 8) != 0 || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8)
         return -1;
     if (splits <= 0 || OA <= 0 || OB <= 0) return -1;
     WgradArgs a;

@@ -25,6 +25,10 @@ __device__ __forceinline__ void st<bf16>(bf16* p, long long i, float v) { p[i] =
 template <>
 __device__ __forceinline__ void st<float>(float* p, long long i, float v) { p[i] = v; }
 
+// Running-max sentinel: finite, so exp(m - m) is 1 (not NaN) when two empty partials are merged and
+// the code stays correct under -ffast-math (which assumes no infinities).
+#define CE_NEG (-3.0e38f)
+
 __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
     const float mn = fmaxf(m, m2);
     s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void ce_fwd_wave_kernel(const T* __restrict__ 
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* x = logits + row * ld_row;
-    float m = -INFINITY, s = 0.f;
+    float m = CE_NEG, s = 0.f;
     for (int i = lane; i < classes; i += 64) {
         const float v = ld<T>(x, i);
         const float mn = fmaxf(m, v);
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void ce_fwd_wave_kernel(const T* __restrict__ 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-        if (m2 > -INFINITY) online_merge(m, s, m2, s2);
+        online_merge(m, s, m2, s2);
     }
     if (lane == 0) {
         const float l = m + __logf(s);
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void ce_fwd_block_kernel(const T* __restrict__
     __shared__ float sm[4], ss[4];
     const int row = blockIdx.x;
     const T* x = logits + row * ld_row;
-    float m = -INFINITY, s = 0.f;
+    float m = CE_NEG, s = 0.f;
     for (int i = threadIdx.x; i < classes; i += 256) {
         const float v = ld<T>(x, i);
         const float mn = fmaxf(m, v);
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void ce_fwd_block_kernel(const T* __restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-        if (m2 > -INFINITY) online_merge(m, s, m2, s2);
+        online_merge(m, s, m2, s2);
     }
     if ((threadIdx.x & 63) == 0) {
         sm[threadIdx.x >> 6] = m;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void ce_fwd_block_kernel(const T* __restrict__
     if (threadIdx.x == 0) {
         float M = sm[0], S = ss[0];
         for (int w = 1; w < 4; ++w)
-            if (sm[w] > -INFINITY) online_merge(M, S, sm[w], ss[w]);
+            online_merge(M, S, sm[w], ss[w]);
         const float l = M + __logf(S);
         const long long y = labels[row];
         lse[row] = l;
