@@ -1,0 +1,432 @@
+// Fused multi-head attention (flash-style, head dim 64) on MFMA for packed QKV activations.
+//
+//   qkv : [B, S, 3, H, 64] bf16  (the output of the fused QKV projection, used in place)
+//   out : [B, S, H, 64]    bf16
+//   lse : [B, H, S]        fp32  log-sum-exp of the scaled scores (natural log), kept for backward
+//
+// The S x S score matrix is never written.  A workgroup (4 waves) owns 64 queries (forward, dQ) or
+// 64 keys (dK/dV); each wave owns 16 of them and walks the other sequence in tiles of 64 staged in
+// LDS.  The MFMA orientation is always chosen so that the reduction index of the *next* product sits
+// on the accumulator registers of the current one: a 16x16 score tile leaves each lane with four
+// values of one column, which - packed to bf16 - is exactly the B-operand fragment of the following
+// MFMA once the other operand is read with the matching row permutation (transposing
+// ds_read_b64_tr_b16).  Softmax statistics are therefore per-lane scalars and P / dS never touch LDS.
+//
+// Not exercised by the reference (CNN only, /root/reference/src/main.py:49); serves ViT-B/16 and GPT-2.
+#include "common.h"
+
+#define AT_D 64
+#define AT_T 64           // tile length along the streamed sequence
+#define AT_PITCH 80       // padded LDS pitch (elements) for tiles read with the transposing load
+#define AT_NEG (-1.0e30f)
+
+typedef __attribute__((address_space(3))) s16x4 at_lds_s16x4;
+
+struct AttnArgs {
+    const bf16* qkv;
+    bf16* out;          // forward: O; backward kernels: unused
+    float* lse;
+    const bf16* dout;   // [B, S, H, 64]
+    const bf16* o;      // [B, S, H, 64]
+    float* delta;       // [B, H, S]
+    bf16* dqkv;         // [B, S, 3, H, 64]
+    int B, S, H;
+    float scale_log2;   // softmax scale * log2(e)
+    float scale;
+    int causal;
+};
+
+__device__ __forceinline__ size_t qkv_off(const AttnArgs& p, int b, int s, int which, int h) {
+    return (((static_cast<size_t>(b) * p.S + s) * 3 + which) * p.H + h) * AT_D;
+}
+
+// 64 x 64 tile, row r from `src + r*stride` for r < valid (zeros otherwise), XOR-swizzled 16-byte chunks
+__device__ __forceinline__ void stage_swz(bf16* dst, const bf16* src, size_t stride, int valid, int tid) {
+    const int chunk = tid & 7, lrow = tid >> 3;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lrow + 32 * i;
+        const bf16x8 v = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
+        *reinterpret_cast<bf16x8*>(dst + row * AT_D + ((chunk ^ (row & 7)) << 3)) = v;
+    }
+}
+
+// same tile in a plain padded layout for transposed reads
+__device__ __forceinline__ void stage_pad(bf16* dst, const bf16* src, size_t stride, int valid, int tid) {
+    const int chunk = tid & 7, lrow = tid >> 3;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lrow + 32 * i;
+        const bf16x8 v = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
+        *reinterpret_cast<bf16x8*>(dst + row * AT_PITCH + chunk * 8) = v;
+    }
+}
+
+__device__ __forceinline__ void stage_both(bf16* dswz, bf16* dpad, const bf16* src, size_t stride, int valid, int tid) {
+    const int chunk = tid & 7, lrow = tid >> 3;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lrow + 32 * i;
+        const bf16x8 v = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
+        *reinterpret_cast<bf16x8*>(dswz + row * AT_D + ((chunk ^ (row & 7)) << 3)) = v;
+        *reinterpret_cast<bf16x8*>(dpad + row * AT_PITCH + chunk * 8) = v;
+    }
+}
+
+// row-major fragment: lane (g, i) gets tile[row0 + i][32*ks + 8g .. +7]
+__device__ __forceinline__ bf16x8 frag_row(const bf16* tile, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15), kc = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + row * AT_D + ((kc ^ (row & 7)) << 3));
+}
+
+// transposed fragment: lane (g, i) gets tile[k0 + kappa(g, j)][col0 + i], kappa(g, j) = 4g + j (j < 4), 16 + 4g + j - 4
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int k0, int col0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const bf16* b0 = tile + (k0 + 4 * g + q) * AT_PITCH + col0 + 4 * pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_s16x4*)(b0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_s16x4*)(b0 + 16 * AT_PITCH));
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// two adjacent 16-row accumulator tiles -> bf16 B-operand fragment with the kappa row order
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = f32_to_bf16(a[e]);
+        r[e + 4] = f32_to_bf16(b[e]);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the four 16-lane groups (same lane & 15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
+    __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 64;
+    const int qrow = q0 + wave * 16 + i;  // this lane's query
+    const size_t srow = static_cast<size_t>(3) * p.H * AT_D;  // elements between consecutive sequence positions
+
+    bf16x8 qf[2];
+    {
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16* qp = p.qkv + qkv_off(p, b, min(qrow, p.S - 1), 0, h);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = qrow < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = AT_NEG, l = 0.f;
+
+    const int kend = p.causal ? min(p.S, q0 + 64) : p.S;
+    for (int k0 = 0; k0 < kend; k0 += AT_T) {
+        __syncthreads();
+        stage_swz(sK, p.qkv + qkv_off(p, b, k0, 1, h), srow, p.S - k0, tid);
+        stage_pad(sV, p.qkv + qkv_off(p, b, k0, 2, h), srow, p.S - k0, tid);
+        __syncthreads();
+        f32x4 s[4];
+        float mx = AT_NEG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t * 16, ks, lane), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + t * 16 + g * 4 + e;
+                const bool ok = key < p.S && (!p.causal || key <= qrow);
+                s[t][e] = ok ? s[t][e] * p.scale_log2 : AT_NEG;
+                mx = fmaxf(mx, s[t][e]);
+            }
+        }
+        mx = group_max(mx);
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = s[t][e] > 0.5f * AT_NEG ? exp2f(s[t][e] - mn) : 0.f;
+                s[t][e] = pv;
+                rs += pv;
+            }
+        rs = group_sum(rs);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, kp * 32, dt * 16, lane),
+                                                                pack_pair(s[2 * kp], s[2 * kp + 1]), o[dt], 0, 0, 0);
+        }
+    }
+    if (qrow < p.S) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        bf16* op = p.out + ((static_cast<size_t>(b) * p.S + qrow) * p.H + h) * AT_D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(o[dt][e] * inv);
+            *reinterpret_cast<bf16x4*>(op + dt * 16 + g * 4) = v;
+        }
+        if (g == 0) p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow] = (m + log2f(fmaxf(l, 1e-30f))) * 0.6931471805599453f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta[b,h,s] = sum_d dO * O   (one wave per (b, s, h) row of 64)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
+    const long long rows = static_cast<long long>(p.B) * p.S * p.H;
+    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float v = bf16_to_f32(p.dout[row * AT_D + lane]) * bf16_to_f32(p.o[row * AT_D + lane]);
+    v = wave_sum(v);
+    if (lane == 0) {
+        const int h = static_cast<int>(row % p.H);
+        const long long bs = row / p.H;
+        const int s = static_cast<int>(bs % p.S), b = static_cast<int>(bs / p.S);
+        p.delta[(static_cast<size_t>(b) * p.H + h) * p.S + s] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: workgroup = 64 keys, wave = 16 keys (key on the lane), streams query tiles.
+//   S[q][key] = Q K^T, dP[q][key] = dO V^T  (accumulators: q on registers, key on lanes)
+//   dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 sQ[AT_T * AT_D];
+    __shared__ __attribute__((aligned(16))) bf16 sQt[AT_T * AT_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16 sDO[AT_T * AT_D];
+    __shared__ __attribute__((aligned(16))) bf16 sDOt[AT_T * AT_PITCH];
+    __shared__ float sLse[AT_T], sDelta[AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int k0 = blockIdx.x * 64;
+    const int key = k0 + wave * 16 + i;
+    const size_t srow = static_cast<size_t>(3) * p.H * AT_D;
+    const size_t orow = static_cast<size_t>(p.H) * AT_D;
+
+    bf16x8 kf[2], vf[2];  // B operands: K^T / V^T fragments of this lane's key
+    {
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int kc = min(key, p.S - 1);
+        const bf16* kp = p.qkv + qkv_off(p, b, kc, 1, h);
+        const bf16* vp = p.qkv + qkv_off(p, b, kc, 2, h);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(kp + ks * 32 + g * 8) : zero8;
+            vf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(vp + ks * 32 + g * 8) : zero8;
+        }
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int qstart = p.causal ? k0 : 0;  // queries before the first key of this tile never attend to it
+    for (int q0 = qstart; q0 < p.S; q0 += AT_T) {
+        __syncthreads();
+        stage_both(sQ, sQt, p.qkv + qkv_off(p, b, q0, 0, h), srow, p.S - q0, tid);
+        stage_both(sDO, sDOt, p.dout + ((static_cast<size_t>(b) * p.S + q0) * p.H + h) * AT_D, orow, p.S - q0, tid);
+        if (tid < AT_T) {
+            const int qq = q0 + tid;
+            const size_t off = (static_cast<size_t>(b) * p.H + h) * p.S + min(qq, p.S - 1);
+            sLse[tid] = qq < p.S ? p.lse[off] * 1.4426950408889634f : 0.f;
+            sDelta[tid] = qq < p.S ? p.delta[off] : 0.f;
+        }
+        __syncthreads();
+        f32x4 pt[4], ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t * 16, ks, lane), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sDO, t * 16, ks, lane), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ql = t * 16 + g * 4 + e, qq = q0 + ql;
+                const bool ok = qq < p.S && key < p.S && (!p.causal || key <= qq);
+                const float pv = ok ? exp2f(s[e] * p.scale_log2 - sLse[ql]) : 0.f;
+                pt[t][e] = pv;
+                ds[t][e] = pv * (dp[e] - sDelta[ql]);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sDOt, kp * 32, dt * 16, lane),
+                                                                 pack_pair(pt[2 * kp], pt[2 * kp + 1]), dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQt, kp * 32, dt * 16, lane),
+                                                                 pack_pair(ds[2 * kp], ds[2 * kp + 1]), dk[dt], 0, 0, 0);
+            }
+    }
+    if (key < p.S) {
+        bf16* dkp = p.dqkv + qkv_off(p, b, key, 1, h);
+        bf16* dvp = p.dqkv + qkv_off(p, b, key, 2, h);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = f32_to_bf16(dk[dt][e] * p.scale);
+                c[e] = f32_to_bf16(dv[dt][e]);
+            }
+            *reinterpret_cast<bf16x4*>(dkp + dt * 16 + g * 4) = a;
+            *reinterpret_cast<bf16x4*>(dvp + dt * 16 + g * 4) = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: workgroup = 64 queries, wave = 16 queries (query on the lane), streams key tiles.
+//   S^T[key][q] = K Q^T, dP^T[key][q] = V dO^T;  dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
+    __shared__ __attribute__((aligned(16))) bf16 sKt[AT_T * AT_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 64;
+    const int qrow = q0 + wave * 16 + i;
+    const size_t srow = static_cast<size_t>(3) * p.H * AT_D;
+
+    bf16x8 qf[2], dof[2];
+    float lse2 = 0.f, delta = 0.f;
+    {
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int qc = min(qrow, p.S - 1);
+        const bf16* qp = p.qkv + qkv_off(p, b, qc, 0, h);
+        const bf16* dop = p.dout + ((static_cast<size_t>(b) * p.S + qc) * p.H + h) * AT_D;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = qrow < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
+            dof[ks] = qrow < p.S ? *reinterpret_cast<const bf16x8*>(dop + ks * 32 + g * 8) : zero8;
+        }
+        if (qrow < p.S) {
+            const size_t off = (static_cast<size_t>(b) * p.H + h) * p.S + qrow;
+            lse2 = p.lse[off] * 1.4426950408889634f;
+            delta = p.delta[off];
+        }
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kend = p.causal ? min(p.S, q0 + 64) : p.S;
+    for (int k0 = 0; k0 < kend; k0 += AT_T) {
+        __syncthreads();
+        stage_both(sK, sKt, p.qkv + qkv_off(p, b, k0, 1, h), srow, p.S - k0, tid);
+        stage_swz(sV, p.qkv + qkv_off(p, b, k0, 2, h), srow, p.S - k0, tid);
+        __syncthreads();
+        f32x4 ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t * 16, ks, lane), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t * 16, ks, lane), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + t * 16 + g * 4 + e;
+                const bool ok = key < p.S && qrow < p.S && (!p.causal || key <= qrow);
+                const float pv = ok ? exp2f(s[e] * p.scale_log2 - lse2) : 0.f;
+                ds[t][e] = pv * (dp[e] - delta);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sKt, kp * 32, dt * 16, lane),
+                                                                 pack_pair(ds[2 * kp], ds[2 * kp + 1]), dq[dt], 0, 0, 0);
+    }
+    if (qrow < p.S) {
+        bf16* dqp = p.dqkv + qkv_off(p, b, qrow, 0, h);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = f32_to_bf16(dq[dt][e] * p.scale);
+            *reinterpret_cast<bf16x4*>(dqp + dt * 16 + g * 4) = a;
+        }
+    }
+}
+
+static int attn_check(int B, int S, int H, int D) {
+    if (B <= 0 || S <= 0 || H <= 0 || D != AT_D) return -1;
+    if (static_cast<long long>(B) * H > 65535ll) return -1;  // grid.y limit
+    if (static_cast<long long>(B) * S * 3 * H * D >= (1ll << 40)) return -1;
+    return 0;
+}
+
+PDT_API int pdt_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int D, float scale, int causal,
+                              void* stream) {
+    if (attn_check(B, S, H, D) != 0) return -1;
+    AttnArgs a = {};
+    a.qkv = static_cast<const bf16*>(qkv);
+    a.out = static_cast<bf16*>(out);
+    a.lse = lse;
+    a.B = B; a.S = S; a.H = H;
+    a.scale = scale;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.causal = causal;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                              int B, int S, int H, int D, float scale, int causal, void* stream) {
+    if (attn_check(B, S, H, D) != 0) return -1;
+    AttnArgs a = {};
+    a.qkv = static_cast<const bf16*>(qkv);
+    a.o = static_cast<const bf16*>(o);
+    a.dout = static_cast<const bf16*>(dout);
+    a.lse = const_cast<float*>(lse);
+    a.delta = delta;
+    a.dqkv = static_cast<bf16*>(dqkv);
+    a.B = B; a.S = S; a.H = H;
+    a.scale = scale;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.causal = causal;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long rows = static_cast<long long>(B) * S * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(pdt_cdiv(rows, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, s, a);
+    return pdt_launch_status();
+}

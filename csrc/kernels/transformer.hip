@@ -1,0 +1,351 @@
+// Transformer support kernels (bf16 activations, fp32 parameters): LayerNorm forward/backward,
+// tanh-GELU forward/backward, bias + residual add, embedding gather and its scatter-add gradient,
+// column sums (bias gradients).  All row-wise passes use one wave per row with 16-byte accesses.
+//
+// Not exercised by the reference (its model is a CNN, /root/reference/src/main.py:49); they serve the
+// ViT-B/16 and GPT-2 data-parallel workloads.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16* __restrict__ y,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + static_cast<size_t>(row) * D;
+    const int nv = D >> 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = bf16_to_f32(xv[e]);
+            s1 += f;
+            s2 += f * f;
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float mean = s1 / D;
+    const float rstd = rsqrtf(fmaxf(s2 / D - mean * mean, 0.f) + eps);
+    if (lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    bf16* yr = y + static_cast<size_t>(row) * D;
+    for (int v = lane; v < nv; v += 64) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = e < 4 ? g0[e] : g1[e - 4], b = e < 4 ? b0[e] : b1[e - 4];
+            o[e] = f32_to_bf16((bf16_to_f32(xv[e]) - mean) * rstd * g + b);
+        }
+        *reinterpret_cast<bf16x8*>(yr + v * 8) = o;
+    }
+}
+
+PDT_API int pdt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                              int rows, int D, float eps, void* stream) {
+    if (rows <= 0 || D <= 0 || (D % 8) != 0) return -1;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(pdt_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(x), gamma, beta, static_cast<bf16*>(y), mean, rstd, rows, D, eps);
+    return pdt_launch_status();
+}
+
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
+// Each wave walks rows row0, row0 + stride, ...; a lane always owns the same columns, so it keeps its
+// dgamma/dbeta partial sums in registers (MAXV vectors of 8 columns), combined per workgroup in LDS
+// and added to the zero-initialised fp32 outputs with one atomic per column.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, bf16* __restrict__ dx,
+                                                           float* dgamma, float* dbeta, int rows, int D) {
+    extern __shared__ float sred[];  // [2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 3;
+    float ag[MAXV][8], ab[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ag[i][e] = ab[i][e] = 0.f;
+    for (int idx = threadIdx.x; idx < 2 * D; idx += 256) sred[idx] = 0.f;
+    __syncthreads();
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const bf16* dyr = dy + static_cast<size_t>(row) * D;
+        const bf16* xr = x + static_cast<size_t>(row) * D;
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dyr + v * 8);
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = gamma[v * 8 + e];
+                    const float d = bf16_to_f32(dv[e]), xh = (bf16_to_f32(xv[e]) - mu) * rs;
+                    c1 += d * g * xh;
+                    c2 += d * g;
+                    ag[i][e] += d * xh;
+                    ab[i][e] += d;
+                }
+            }
+        }
+        c1 = wave_sum(c1) / D;
+        c2 = wave_sum(c2) / D;
+        bf16* dxr = dx + static_cast<size_t>(row) * D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dyr + v * 8);
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = gamma[v * 8 + e];
+                    const float xh = (bf16_to_f32(xv[e]) - mu) * rs;
+                    o[e] = f32_to_bf16(rs * (bf16_to_f32(dv[e]) * g - c2 - xh * c1));
+                }
+                *reinterpret_cast<bf16x8*>(dxr + v * 8) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(&sred[v * 8 + e], ag[i][e]);
+                atomicAdd(&sred[D + v * 8 + e], ab[i][e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < D; idx += 256) {
+        __hip_atomic_fetch_add(dgamma + idx, sred[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(dbeta + idx, sred[D + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// dgamma / dbeta must be zero-initialised.
+PDT_API int pdt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                              void* dx, float* dgamma, float* dbeta, int rows, int D, void* stream) {
+    if (rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * 64 * 8) return -1;
+    const int nv = D / 8, maxv = (nv + 63) / 64;
+    int grid = pdt_cdiv(rows, 4);
+    if (grid > 512) grid = 512;
+    const size_t lds = 2ull * D * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16 *pdy = static_cast<const bf16*>(dy), *px = static_cast<const bf16*>(x);
+    bf16* pdx = static_cast<bf16*>(dx);
+#define PDT_LN(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), lds, s, pdy, px, gamma, mean, rstd, pdx, dgamma, dbeta, rows, D)
+    if (maxv <= 1) PDT_LN(1);
+    else if (maxv <= 2) PDT_LN(2);
+    else if (maxv <= 4) PDT_LN(4);
+    else PDT_LN(8);
+#undef PDT_LN
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GELU (tanh form)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float x2 = x * x;
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+    const float t = tanhf(u);
+    const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long nvec) {
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + v * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(gelu_f(bf16_to_f32(xv[e])));
+        *reinterpret_cast<bf16x8*>(y + v * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ g, const bf16* __restrict__ x,
+                                                      bf16* __restrict__ dx, long long nvec) {
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + v * 8);
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + v * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(bf16_to_f32(gv[e]) * gelu_grad_f(bf16_to_f32(xv[e])));
+        *reinterpret_cast<bf16x8*>(dx + v * 8) = o;
+    }
+}
+
+static inline int ew_grid8(long long nvec) {
+    long long g = (nvec + 255) / 256;
+    return static_cast<int>(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+PDT_API int pdt_gelu_fwd(const void* x, void* y, long long numel, void* stream) {
+    if (numel <= 0 || (numel % 8) != 0) return -1;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid8(numel / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(x), static_cast<bf16*>(y), numel / 8);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_gelu_bwd(const void* g, const void* x, void* dx, long long numel, void* stream) {
+    if (numel <= 0 || (numel % 8) != 0) return -1;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid8(numel / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(g), static_cast<const bf16*>(x), static_cast<bf16*>(dx), numel / 8);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = x (+ bias[col]) (+ residual)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_residual_kernel(const bf16* __restrict__ x, const float* __restrict__ bias,
+                                                           const bf16* __restrict__ res, bf16* __restrict__ out,
+                                                           long long nvec, int D) {
+    const int dvec = D >> 3;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int c = static_cast<int>(v % dvec) << 3;
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + v * 8);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(xv[e]);
+        if (bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += bias[c + e];
+        }
+        if (res != nullptr) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += bf16_to_f32(rv[e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(f[e]);
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+    }
+}
+
+PDT_API int pdt_bias_residual(const void* x, const float* bias, const void* res, void* out, long long numel, int D,
+                              void* stream) {
+    if (numel <= 0 || D <= 0 || (D % 8) != 0 || (numel % D) != 0) return -1;
+    hipLaunchKernelGGL(bias_residual_kernel, dim3(ew_grid8(numel / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(x), bias, static_cast<const bf16*>(res), static_cast<bf16*>(out), numel / 8, D);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of a bf16 [rows, ld] matrix -> fp32 out[cols] (zero-initialised); used for bias gradients
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* out, int rows, int cols, int ld,
+                                                    int rows_per_block) {
+    __shared__ float red[32][64];
+    const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.y * 64 + chunk * 8;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (c < cols) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + static_cast<size_t>(r) * ld + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf16_to_f32(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][chunk * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+        const int cc = blockIdx.y * 64 + threadIdx.x;
+        if (cc < cols) __hip_atomic_fetch_add(out + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// reads whole 8-column chunks: ld must be >= cols rounded up to 8
+PDT_API int pdt_colsum(const void* x, float* out, int rows, int cols, int ld, void* stream) {
+    if (rows <= 0 || cols <= 0 || (ld % 8) != 0 || ld < (cols + 7) / 8 * 8) return -1;
+    const int groups = pdt_cdiv(cols, 64);
+    int bx = 1024 / groups;
+    if (bx < 1) bx = 1;
+    int rpb = pdt_cdiv(rows, bx);
+    rpb = pdt_cdiv(rpb, 32) * 32;
+    hipLaunchKernelGGL(colsum_kernel, dim3(pdt_cdiv(rows, rpb), groups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(x), out, rows, cols, ld, rpb);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding: out[i] = bf16(W[ids[i]]);  dW[ids[i]] += g[i]  (fp32 atomics, dW zero-initialised)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ w,
+                                                           bf16* __restrict__ out, long long n, int D, long long vocab) {
+    const int dvec = D >> 3;
+    const long long nvec = n * dvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const long long i = v / dvec;
+        const int c = static_cast<int>(v - i * dvec) << 3;
+        long long id = ids[i];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + id * D + c), b = *reinterpret_cast<const f32x4*>(w + id * D + c + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = f32_to_bf16(a[e]);
+            o[e + 4] = f32_to_bf16(b[e]);
+        }
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const bf16* __restrict__ g,
+                                                           float* dw, long long n, int D, long long vocab) {
+    const int dvec = D >> 3;
+    const long long nvec = n * dvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const long long i = v / dvec;
+        const int c = static_cast<int>(v - i * dvec) << 3;
+        const long long id = ids[i];
+        if (id < 0 || id >= vocab) continue;
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            __hip_atomic_fetch_add(dw + id * D + c + e, bf16_to_f32(gv[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+PDT_API int pdt_embedding_fwd(const long long* ids, const float* w, void* out, long long n, int D, long long vocab,
+                              void* stream) {
+    if (n <= 0 || D <= 0 || (D % 8) != 0 || vocab <= 0) return -1;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_grid8(n * (D / 8))), dim3(256), 0, static_cast<hipStream_t>(stream), ids, w,
+                       static_cast<bf16*>(out), n, D, vocab);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_embedding_bwd(const long long* ids, const void* g, float* dw, long long n, int D, long long vocab,
+                              void* stream) {
+    if (n <= 0 || D <= 0 || (D % 8) != 0 || vocab <= 0) return -1;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_grid8(n * (D / 8))), dim3(256), 0, static_cast<hipStream_t>(stream), ids,
+                       static_cast<const bf16*>(g), dw, n, D, vocab);
+    return pdt_launch_status();
+}

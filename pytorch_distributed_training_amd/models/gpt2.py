@@ -69,4 +69,4 @@ def gpt2_small(vocab_size: int = 50257, n_ctx: int = 1024) -> GPT2:
 
 def gpt2_tiny(vocab_size: int = 512, n_ctx: int = 64) -> GPT2:
     """Small configuration for tests."""
-    return GPT2(vocab_size, n_ctx, 64, 2, 2)
+    return GPT2(vocab_size, n_ctx, 128, 2, 2)

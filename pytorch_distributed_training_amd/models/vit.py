@@ -38,11 +38,8 @@ class SelfAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
 
     def forward(self, x, residual):
-        b, s, d = x.shape
-        h, dh = self.heads, d // self.heads
-        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias).view(b, s, 3, h, dh)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))  # [b, h, s, dh] views
-        o = ops.attention(q, k, v, causal=self.causal).transpose(1, 2).reshape(b, s, d)
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)  # [b, s, 3*d], consumed in place by the attention kernel
+        o = ops.attention_qkv(qkv, self.heads, causal=self.causal)
         return ops.add_bias_residual(ops.linear(o, self.proj.weight, None), self.proj.bias, residual)
 
 
@@ -106,4 +103,4 @@ def vit_b_16(num_classes: int = 1000, image_size: int = 224) -> VisionTransforme
 
 def vit_tiny(num_classes: int = 10, image_size: int = 32) -> VisionTransformer:
     """Small configuration for tests."""
-    return VisionTransformer(image_size, 8, 64, 2, 2, 128, num_classes)
+    return VisionTransformer(image_size, 8, 128, 2, 2, 256, num_classes)

@@ -94,6 +94,13 @@ def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
     return _ref.attention(q, k, v, causal, scale)
 
 
+def attention_qkv(qkv, heads: int, causal: bool = False):
+    """Self-attention on the packed QKV projection ``[B, S, 3*H*Dh]`` -> ``[B, S, H*Dh]``."""
+    if qkv.is_cuda:
+        return _hip().attention_qkv(qkv, heads, causal)
+    return _ref.attention_qkv(qkv, heads, causal)
+
+
 def embedding(ids, weight):
     if weight.is_cuda:
         return _hip().embedding(ids, weight)

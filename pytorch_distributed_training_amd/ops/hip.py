@@ -764,6 +764,12 @@ def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
     return ht.attention(q, k, v, causal, scale)
 
 
+def attention_qkv(qkv, heads: int, causal: bool = False):
+    from . import hip_transformer as ht
+
+    return ht.attention_qkv(qkv, heads, causal)
+
+
 def embedding(ids, weight):
     from . import hip_transformer as ht
 

@@ -1,27 +1,194 @@
-"""GPU transformer operators (LayerNorm, GELU, attention, embedding, bias+residual)."""
+"""GPU transformer operators: LayerNorm, GELU, fused attention, embedding, bias+residual.
+
+Thin ``autograd.Function`` wrappers over ``csrc/kernels/transformer.hip`` and
+``csrc/kernels/attention.hip``.  Activations are bf16, parameters and their gradients fp32.
+Not exercised by the reference (its model is a CNN, /root/reference/src/main.py:49).
+"""
 
 from __future__ import annotations
 
+import ctypes
+import math
+from typing import Optional
 
-def _todo(name):
-    raise NotImplementedError(f"HIP kernel for {name} is not built yet")
+import torch
+
+from .hip import _check, _lib, _ptr, _stream
+
+_vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 
-def layer_norm(x, weight, bias, eps):
-    _todo("layer_norm")
+def _sig(name, argtypes):
+    fn = getattr(_lib, name)
+    fn.argtypes = argtypes
+    fn.restype = ctypes.c_int
+    return fn
+
+
+_ln_fwd = _sig("pdt_layernorm_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp])
+_ln_bwd = _sig("pdt_layernorm_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp])
+_gelu_fwd = _sig("pdt_gelu_fwd", [_vp, _vp, _ll, _vp])
+_gelu_bwd = _sig("pdt_gelu_bwd", [_vp, _vp, _vp, _ll, _vp])
+_bias_res = _sig("pdt_bias_residual", [_vp, _vp, _vp, _vp, _ll, _i, _vp])
+_colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
+_emb_fwd = _sig("pdt_embedding_fwd", [_vp, _vp, _vp, _ll, _i, _ll, _vp])
+_emb_bwd = _sig("pdt_embedding_bwd", [_vp, _vp, _vp, _ll, _i, _ll, _vp])
+_attn_fwd = _sig("pdt_attention_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp])
+_attn_bwd = _sig("pdt_attention_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp])
+
+
+def _bf16c(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        x = _bf16c(x)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _check(_ln_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                       rows, d, eps, _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, rstd = ctx.saved_tensors
+        g = _bf16c(g)
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dgb = torch.zeros((2, d), dtype=torch.float32, device=x.device)
+        _check(_ln_bwd(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                       dgb[0].data_ptr(), dgb[1].data_ptr(), rows, d, _stream()), "layernorm_bwd")
+        return dx, dgb[0], dgb[1], None
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _bf16c(x)
+        y = torch.empty_like(x)
+        _check(_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _bf16c(g)
+        dx = torch.empty_like(x)
+        _check(_gelu_bwd(g.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "gelu_bwd")
+        return dx
 
 
 def gelu(x):
-    _todo("gelu")
+    return _Gelu.apply(x)
 
 
-def attention(q, k, v, causal, scale):
-    _todo("attention")
+class _BiasResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, residual):
+        x = _bf16c(x)
+        d = x.shape[-1]
+        res = _bf16c(residual) if residual is not None else None
+        out = torch.empty_like(x)
+        _check(_bias_res(x.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), x.numel(), d, _stream()), "bias_residual")
+        ctx.meta = (bias is not None, residual is not None, d)
+        return out
 
-
-def embedding(ids, weight):
-    _todo("embedding")
+    @staticmethod
+    def backward(ctx, g):
+        has_bias, has_res, d = ctx.meta
+        db = None
+        if has_bias and ctx.needs_input_grad[1]:
+            g2 = _bf16c(g)
+            rows = g2.numel() // d
+            db = torch.zeros(d, dtype=torch.float32, device=g.device)
+            _check(_colsum(g2.data_ptr(), db.data_ptr(), rows, d, d, _stream()), "colsum")
+        return g, db, (g if has_res else None)
 
 
 def add_bias_residual(x, bias, residual):
-    _todo("add_bias_residual")
+    if bias is None and residual is None:
+        return x
+    return _BiasResidual.apply(x, bias, residual)
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight):
+        ids_c = ids.reshape(-1).to(torch.int64).contiguous()
+        vocab, d = weight.shape
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        out = torch.empty((ids_c.numel(), d), dtype=torch.bfloat16, device=weight.device)
+        _check(_emb_fwd(ids_c.data_ptr(), w.data_ptr(), out.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_fwd")
+        ctx.save_for_backward(ids_c)
+        ctx.meta = (vocab, d)
+        return out.reshape(*ids.shape, d)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids_c,) = ctx.saved_tensors
+        vocab, d = ctx.meta
+        g2 = _bf16c(g).reshape(-1, d)
+        dw = torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
+        _check(_emb_bwd(ids_c.data_ptr(), g2.data_ptr(), dw.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_bwd")
+        return None, dw
+
+
+def embedding(ids, weight):
+    return _Embedding.apply(ids, weight)
+
+
+class _AttentionQKV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads: int, causal: bool):
+        qkv = _bf16c(qkv)
+        b, s, three_d = qkv.shape
+        d = three_d // 3
+        dh = d // heads
+        if dh != 64 or heads * dh * 3 != three_d:
+            raise ValueError("the attention kernel needs head_dim == 64")
+        out = torch.empty((b, s, d), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((b, heads, s), dtype=torch.float32, device=qkv.device)
+        scale = 1.0 / math.sqrt(dh)
+        _check(_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), b, s, heads, dh, scale, int(causal), _stream()),
+               "attention_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.meta = (b, s, heads, dh, scale, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, out, lse = ctx.saved_tensors
+        b, s, heads, dh, scale, causal = ctx.meta
+        g = _bf16c(g)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty((b, heads, s), dtype=torch.float32, device=qkv.device)
+        _check(_attn_bwd(qkv.data_ptr(), out.data_ptr(), g.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), b, s,
+                         heads, dh, scale, int(causal), _stream()), "attention_bwd")
+        return dqkv, None, None
+
+
+def attention_qkv(qkv, heads: int, causal: bool = False):
+    return _AttentionQKV.apply(qkv, heads, causal)
+
+
+def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
+    """[B, H, S, 64] q/k/v -> [B, H, S, 64]; packs into the layout the fused kernel reads."""
+    b, h, s, dh = q.shape
+    if scale is not None and abs(scale - 1.0 / math.sqrt(dh)) > 1e-9:
+        raise ValueError("the fused attention kernel uses scale = 1/sqrt(head_dim)")
+    qkv = torch.stack([t.transpose(1, 2) for t in (q, k, v)], dim=2).reshape(b, s, 3 * h * dh)
+    return attention_qkv(qkv, h, causal).view(b, s, h, dh).transpose(1, 2)

@@ -96,6 +96,16 @@ def attention(q, k, v, causal: bool = False, scale: Optional[float] = None):
     return torch.matmul(p, v.float()).to(q.dtype)
 
 
+def attention_qkv(qkv, heads: int, causal: bool = False):
+    """Multi-head self-attention on the packed projection output ``[B, S, 3*H*Dh]`` -> ``[B, S, H*Dh]``."""
+    b, s, three_d = qkv.shape
+    d = three_d // 3
+    dh = d // heads
+    x = qkv.view(b, s, 3, heads, dh)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    return attention(q, k, v, causal).transpose(1, 2).reshape(b, s, d)
+
+
 def embedding(ids, weight):
     return F.embedding(ids, weight)
 

@@ -1,0 +1,141 @@
+"""Numerics of the transformer HIP kernels against PyTorch fp32 references (needs an MI355X)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ht():
+    from pytorch_distributed_training_amd.ops import hip_transformer as m
+
+    return m
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+@pytest.mark.parametrize("rows,d", [(197 * 3, 768), (64, 1024), (50, 64), (17, 3072)])
+def test_layer_norm(ht, rows, d):
+    torch.manual_seed(0)
+    dev = _dev()
+    x = (torch.randn(rows, d, device=dev) * 2 + 0.5).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.rand(d, device=dev) + 0.5).requires_grad_(True)
+    b = torch.randn(d, device=dev).requires_grad_(True)
+    y = ht.layer_norm(x, w, b, 1e-5)
+    xr = x.detach().float().requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (d,), wr, br, 1e-5)
+    assert _rel(y, ref) < 6e-3
+    g = torch.randn_like(ref)
+    y.backward(g.to(torch.bfloat16))
+    ref.backward(_r(g))
+    assert _rel(x.grad, xr.grad) < 1e-2
+    assert _rel(w.grad, wr.grad) < 1e-2
+    assert _rel(b.grad, br.grad) < 1e-2
+
+
+def test_gelu_and_bias_residual(ht):
+    torch.manual_seed(1)
+    dev = _dev()
+    x = (torch.randn(33, 256, device=dev) * 2).to(torch.bfloat16).requires_grad_(True)
+    y = ht.gelu(x)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.gelu(xr, approximate="tanh")
+    assert _rel(y, ref) < 6e-3
+    y.backward(torch.ones_like(y))
+    ref.backward(torch.ones_like(ref))
+    assert _rel(x.grad, xr.grad) < 8e-3
+    a = torch.randn(40, 128, device=dev).to(torch.bfloat16).requires_grad_(True)
+    res = torch.randn(40, 128, device=dev).to(torch.bfloat16).requires_grad_(True)
+    bias = torch.randn(128, device=dev).requires_grad_(True)
+    out = ht.add_bias_residual(a, bias, res)
+    assert _rel(out, a.float() + bias + res.float()) < 6e-3
+    g = torch.randn(40, 128, device=dev).to(torch.bfloat16)
+    out.backward(g)
+    assert torch.equal(a.grad, g) and torch.equal(res.grad, g)
+    assert _rel(bias.grad, g.float().sum(0)) < 1e-3
+
+
+def test_embedding(ht):
+    torch.manual_seed(2)
+    dev = _dev()
+    w = torch.randn(100, 64, device=dev).requires_grad_(True)
+    ids = torch.randint(0, 100, (4, 9), device=dev)
+    out = ht.embedding(ids, w)
+    assert out.shape == (4, 9, 64)
+    assert torch.equal(out, w.detach()[ids].to(torch.bfloat16))
+    g = torch.randn(4, 9, 64, device=dev).to(torch.bfloat16)
+    out.backward(g)
+    ref = torch.zeros_like(w)
+    ref.index_put_((ids.reshape(-1),), g.float().reshape(-1, 64), accumulate=True)
+    assert _rel(w.grad, ref) < 1e-5
+
+
+@pytest.mark.parametrize("b,s,h,causal", [(2, 197, 3, False), (2, 256, 4, True), (1, 130, 2, True), (3, 64, 1, False)])
+def test_attention_forward_backward(ht, b, s, h, causal):
+    from pytorch_distributed_training_amd.ops import reference as ref_ops
+
+    torch.manual_seed(3)
+    dev = _dev()
+    d = h * 64
+    qkv = torch.randn(b, s, 3 * d, device=dev).to(torch.bfloat16).requires_grad_(True)
+    out = ht.attention_qkv(qkv, h, causal)
+    qr = qkv.detach().float().requires_grad_(True)
+    ref = ref_ops.attention_qkv(qr, h, causal)
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < 1e-2
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(_r(g))
+    dq, dk, dv = (qkv.grad.view(b, s, 3, d)[:, :, i] for i in range(3))
+    rq, rk, rv = (qr.grad.view(b, s, 3, d)[:, :, i] for i in range(3))
+    assert _rel(dv, rv) < 1.5e-2
+    assert _rel(dk, rk) < 2e-2
+    assert _rel(dq, rq) < 2e-2
+
+
+def test_vit_and_gpt2_tiny_train_on_gpu():
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    torch.manual_seed(4)
+    dev = _dev()
+    vit = build_model("vit_tiny").to(dev)
+    opt = FusedOptimizer(vit.parameters(), mode="adamw", lr=3e-3, weight_decay=0.01)
+    x = ops.to_device_layout(torch.randn(16, 3, 32, 32, device=dev))
+    y = torch.randint(0, 10, (16,), device=dev)
+    losses = []
+    for _ in range(15):
+        opt.zero_grad()
+        l = ops.softmax_cross_entropy(vit(x), y)
+        l.backward()
+        opt.step()
+        losses.append(float(l.detach()))
+    assert losses[-1] < 0.7 * losses[0], losses
+    gpt = build_model("gpt2_tiny").to(dev)
+    opt = FusedOptimizer(gpt.parameters(), mode="adamw", lr=3e-3, weight_decay=0.01)
+    ids = torch.randint(0, 512, (4, 64), device=dev)
+    tg = torch.randint(0, 512, (4, 64), device=dev)
+    losses = []
+    for _ in range(15):
+        opt.zero_grad()
+        l = gpt(ids, tg)
+        l.backward()
+        opt.step()
+        losses.append(float(l.detach()))
+    assert abs(losses[0] - math.log(512)) < 0.7
+    assert losses[-1] < 0.85 * losses[0], losses
