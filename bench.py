@@ -29,7 +29,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-size", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch-size", type=int, default=512, help="per-GPU batch (sized for 288 GB of HBM)")
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=1024)
@@ -59,7 +59,7 @@ def main():
     model = build_model(args.model, 1000, args.image_size).to(dev)
     if on_gpu:
         model = model.to(memory_format=torch.channels_last)
-    raw = model
+    raw = ops.prepare_module(model)
     if env.distributed:
         model = wrap_data_parallel(model, env, bucket_mb=args.bucket_mb)
     opt_name = args.optimizer or ("adamw" if (is_lm or args.model.startswith("vit")) else "sgd")

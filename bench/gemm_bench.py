@@ -1,0 +1,50 @@
+"""Raw throughput of the MFMA GEMM core (the convolution kernel with a single tap) on square and
+skinny problems, random bf16 operands.
+
+    python bench/gemm_bench.py
+"""
+from __future__ import annotations
+
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+SHAPES = [(4096, 4096, 4096), (8192, 8192, 8192), (50176, 256, 2304), (50176, 1024, 256), (50176, 256, 1024),
+          (802816, 64, 576), (802816, 256, 64), (200704, 128, 1152), (12544, 512, 4608), (12544, 2048, 512),
+          (8192, 3072, 768), (8192, 50304, 1024)]
+
+
+def main():
+    from pytorch_distributed_training_amd.ops import hip
+
+    dev = torch.device("cuda", 0)
+    print(f"{'M':>8}{'N':>7}{'K':>6}{'us':>10}{'TF/s':>8}")
+    for m, n, k in SHAPES:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        b = torch.randn(n, k, device=dev).to(torch.bfloat16)
+        out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+
+        def run():
+            hip._launch_gather_gemm(a, b, out, None, None, m, n, k, n, k, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        t = statistics.median(ts)
+        print(f"{m:8d}{n:7d}{k:6d}{t * 1e6:10.1f}{2.0 * m * n * k / t / 1e12:8.1f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -135,7 +135,8 @@ PDT_API int pdt_bn_apply_fwd(const void* y, const float* consts, const void* ide
 // backward reduction:  slots[S][3][C] += (sum dz, sum dz*xhat, sum dz*xhat2),  dz = dout * [out > 0]
 //   workgroup = 32 row-lanes x 8 chunks (64 channels); grid.x = row blocks, grid.y = channel groups
 // ------------------------------------------------------------------------------------------------
-template <bool MASK, bool SECOND>
+// MASK: 0 = dz is dout, 1 = mask from the stored output (out > 0), 2 = mask recomputed as y*scale + shift > 0
+template <int MASK, bool SECOND>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
                                                            const bf16* __restrict__ y, const float* __restrict__ consts,
                                                            const bf16* __restrict__ y2,
@@ -145,10 +146,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
     const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.y * 64 + chunk * 8;
     const bool cok = c < C;
-    float mu[8], rs[8], mu2[8], rs2[8];
+    float mu[8], rs[8], mu2[8], rs2[8], sc[8], sh[8];
     if (cok) {
         load8f(consts + c, mu);
         load8f(consts + C + c, rs);
+        if (MASK == 2) {
+            load8f(consts + 2 * C + c, sc);
+            load8f(consts + 3 * C + c, sh);
+        }
         if (SECOND) {
             load8f(consts2 + c, mu2);
             load8f(consts2 + C + c, rs2);
@@ -165,14 +170,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
             const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + off);
             const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + off);
             bf16x8 ov, y2v;
-            if (MASK) ov = *reinterpret_cast<const bf16x8*>(out + off);
+            if (MASK == 1) ov = *reinterpret_cast<const bf16x8*>(out + off);
             if (SECOND) y2v = *reinterpret_cast<const bf16x8*>(y2 + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float dz = bf16_to_f32(dv[e]);
-                if (MASK) dz = bf16_to_f32(ov[e]) > 0.f ? dz : 0.f;
+                const float yf = bf16_to_f32(yv[e]);
+                if (MASK == 1) dz = bf16_to_f32(ov[e]) > 0.f ? dz : 0.f;
+                if (MASK == 2) dz = (yf * sc[e] + sh[e]) > 0.f ? dz : 0.f;
                 s1[e] += dz;
-                s2[e] += dz * (bf16_to_f32(yv[e]) - mu[e]) * rs[e];
+                s2[e] += dz * (yf - mu[e]) * rs[e];
                 if (SECOND) s3[e] += dz * (bf16_to_f32(y2v[e]) - mu2[e]) * rs2[e];
             }
         }
@@ -207,20 +214,21 @@ static inline int reduce_rows_per_block(int M, int C) {
     return static_cast<int>(rpb < 32 ? 32 : rpb);
 }
 
-// slots: zero-initialised [PDT_STAT_SLOTS][3][C]
+// slots: zero-initialised [PDT_STAT_SLOTS][3][C].  mask_mode: 0 none, 1 from `out`, 2 recomputed from y.
 PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, const float* consts, const void* y2,
-                              const float* consts2, float* slots, int M, int C, void* stream) {
-    if (M <= 0 || C <= 0 || (C % 8) != 0) return -1;
+                              const float* consts2, float* slots, int M, int C, int mask_mode, void* stream) {
+    if (M <= 0 || C <= 0 || (C % 8) != 0 || mask_mode < 0 || mask_mode > 2 || (mask_mode == 1 && out == nullptr)) return -1;
     const int rpb = reduce_rows_per_block(M, C);
     const dim3 g(pdt_cdiv(M, rpb), pdt_cdiv(C, 64)), b(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16 *d = static_cast<const bf16*>(dout), *o = static_cast<const bf16*>(out), *yy = static_cast<const bf16*>(y),
                *yy2 = static_cast<const bf16*>(y2);
-    const bool mask = out != nullptr, second = y2 != nullptr;
-    if (mask && second) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
-    else if (mask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
-    else if (second) hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, true>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb);
+    const bool second = y2 != nullptr;
+#define PDT_RED(MK, SC) hipLaunchKernelGGL((bn_bwd_reduce_kernel<MK, SC>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb)
+    if (mask_mode == 1) { if (second) PDT_RED(1, true); else PDT_RED(1, false); }
+    else if (mask_mode == 2) { if (second) PDT_RED(2, true); else PDT_RED(2, false); }
+    else { if (second) PDT_RED(0, true); else PDT_RED(0, false); }
+#undef PDT_RED
     return pdt_launch_status();
 }
 
@@ -260,9 +268,10 @@ PDT_API int pdt_bn_bwd_finalize(const float* slots, int C, int which, float coun
 // ------------------------------------------------------------------------------------------------
 // bn_bwd_apply:  dz = dout*[out>0];  dy = c0*dz + c1*y + c2;  optional dz store; optional second dy2
 // ------------------------------------------------------------------------------------------------
-template <bool MASK, bool WRITE_DZ, bool SECOND>
+template <int MASK, bool WRITE_DZ, bool SECOND>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ y, const float* __restrict__ coef,
+                                                          const float* __restrict__ consts,
                                                           bf16* __restrict__ dy, bf16* __restrict__ dz_out,
                                                           const bf16* __restrict__ y2, const float* __restrict__ coef2,
                                                           bf16* __restrict__ dy2, long long nvec, int C) {
@@ -276,10 +285,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
         const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + v * 8);
         const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + v * 8);
         float dz[8];
-        if (MASK) {
+        if (MASK == 1) {
             const bf16x8 ov = *reinterpret_cast<const bf16x8*>(out + v * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dz[e] = bf16_to_f32(ov[e]) > 0.f ? bf16_to_f32(dv[e]) : 0.f;
+        } else if (MASK == 2) {
+            float sc[8], sh[8];
+            load8f(consts + 2 * C + c, sc);
+            load8f(consts + 3 * C + c, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dz[e] = (bf16_to_f32(yv[e]) * sc[e] + sh[e]) > 0.f ? bf16_to_f32(dv[e]) : 0.f;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dz[e] = bf16_to_f32(dv[e]);
@@ -308,9 +323,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     }
 }
 
-PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, const float* coef, void* dy, void* dz_out,
-                             const void* y2, const float* coef2, void* dy2, long long numel, int C, void* stream) {
+// mask_mode as in pdt_bn_bwd_reduce; `consts` ([4][C] from bn_finalize) is needed for mask_mode 2.
+PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, const float* coef, const float* consts,
+                             void* dy, void* dz_out, const void* y2, const float* coef2, void* dy2, long long numel,
+                             int C, int mask_mode, void* stream) {
     if (C <= 0 || (C % 8) != 0 || numel <= 0 || (numel % C) != 0) return -1;
+    if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 1 && out == nullptr) || (mask_mode == 2 && consts == nullptr)) return -1;
     if (dz_out != nullptr && y2 != nullptr) return -1;  // identity is either plain (needs dz) or projected (needs dy2)
     const long long nvec = numel / 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -318,18 +336,18 @@ PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, c
     const bf16 *d = static_cast<const bf16*>(dout), *o = static_cast<const bf16*>(out), *yy = static_cast<const bf16*>(y),
                *yy2 = static_cast<const bf16*>(y2);
     bf16 *pdy = static_cast<bf16*>(dy), *pdz = static_cast<bf16*>(dz_out), *pdy2 = static_cast<bf16*>(dy2);
-    const bool mask = out != nullptr;
 #define PDT_APPLY(MK, WZ, SC) \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, WZ, SC>), g, b, 0, s, d, o, yy, coef, pdy, pdz, yy2, coef2, pdy2, nvec, C)
-    if (mask) {
-        if (dz_out != nullptr) PDT_APPLY(true, true, false);
-        else if (y2 != nullptr) PDT_APPLY(true, false, true);
-        else PDT_APPLY(true, false, false);
-    } else {
-        if (dz_out != nullptr) PDT_APPLY(false, true, false);
-        else if (y2 != nullptr) PDT_APPLY(false, false, true);
-        else PDT_APPLY(false, false, false);
-    }
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, WZ, SC>), g, b, 0, s, d, o, yy, coef, consts, pdy, pdz, yy2, coef2, pdy2, nvec, C)
+#define PDT_APPLY_M(MK)                                   \
+    do {                                                  \
+        if (dz_out != nullptr) PDT_APPLY(MK, true, false); \
+        else if (y2 != nullptr) PDT_APPLY(MK, false, true); \
+        else PDT_APPLY(MK, false, false);                 \
+    } while (0)
+    if (mask_mode == 1) PDT_APPLY_M(1);
+    else if (mask_mode == 2) PDT_APPLY_M(2);
+    else PDT_APPLY_M(0);
+#undef PDT_APPLY_M
 #undef PDT_APPLY
     return pdt_launch_status();
 }

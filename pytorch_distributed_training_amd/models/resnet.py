@@ -48,11 +48,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y1, s1 = ops.conv2d_stats(x, self.conv1.weight, self.conv1.s, self.conv1.p)
+        y1, s1 = ops.conv2d_stats(x, self.conv1.weight, self.conv1.s, self.conv1.p, self.training)
         y2, s2 = ops.bn_relu_conv2d(y1, s1, self.bn1, self.conv2.weight, 1, 1)
         if self.downsample is not None:
             dconv, dbn = self.downsample[0], self.downsample[1]
-            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p)
+            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p, self.training)
             return ops.bn_add_relu(y2, s2, self.bn2, yd, sd, dbn)
         return ops.bn_add_relu(y2, s2, self.bn2, x)
 
@@ -71,12 +71,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y1, s1 = ops.conv2d_stats(x, self.conv1.weight, 1, 0)
+        y1, s1 = ops.conv2d_stats(x, self.conv1.weight, 1, 0, self.training)
         y2, s2 = ops.bn_relu_conv2d(y1, s1, self.bn1, self.conv2.weight, self.conv2.s, 1)
         y3, s3 = ops.bn_relu_conv2d(y2, s2, self.bn2, self.conv3.weight, 1, 0)
         if self.downsample is not None:
             dconv, dbn = self.downsample[0], self.downsample[1]
-            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p)
+            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p, self.training)
             return ops.bn_add_relu(y3, s3, self.bn3, yd, sd, dbn)
         return ops.bn_add_relu(y3, s3, self.bn3, x)
 
@@ -120,7 +120,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y0, s0 = ops.conv2d_stats(x, self.conv1.weight, 2, 3)
+        y0, s0 = ops.conv2d_stats(x, self.conv1.weight, 2, 3, self.training)
         a = ops.bn_relu_maxpool(y0, s0, self.bn1)
         a = self.layer1(a)
         a = self.layer2(a)

@@ -22,11 +22,12 @@ def _hip():
     return hip
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0):
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True):
     """Convolution without bias.  Returns ``(y, stats)`` where ``stats`` carries the per-channel
-    batch statistics of ``y`` gathered in the kernel epilogue (``None`` on CPU)."""
+    batch statistics of ``y`` gathered in the kernel epilogue (``None`` on CPU or when not wanted,
+    e.g. in inference where BatchNorm uses its running statistics)."""
     if x.is_cuda:
-        return _hip().conv2d_stats(x, weight, stride, padding)
+        return _hip().conv2d_stats(x, weight, stride, padding, want_stats)
     return _ref.conv2d_stats(x, weight, stride, padding)
 
 
@@ -111,6 +112,15 @@ def add_bias_residual(x, bias, residual):
     if x.is_cuda:
         return _hip().add_bias_residual(x, bias, residual)
     return _ref.add_bias_residual(x, bias, residual)
+
+
+def prepare_module(module):
+    """One-time per-model setup of the GPU path (no-op for CPU modules): lets weight-gradient kernels
+    accumulate directly into ``.grad`` where that is safe."""
+    p = next(module.parameters(), None)
+    if p is not None and p.is_cuda:
+        _hip().enable_grad_sink(module)
+    return module
 
 
 def to_device_layout(x, dtype=torch.bfloat16):

@@ -44,9 +44,9 @@ _gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
-_bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp])
+_bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
 _bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp])
-_bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp])
+_bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_relu_maxpool_fwd = _sig("pdt_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _maxpool_bn_bwd_reduce = _sig("pdt_maxpool_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _avgpool_fwd = _sig("pdt_avgpool_fwd", [_vp, _vp, _i, _i, _i, _vp])
@@ -87,6 +87,100 @@ def _round_up(x: int, m: int) -> int:
 
 def _int_array(vals: Sequence[int]):
     return (ctypes.c_int * max(len(vals), 1))(*vals)
+
+
+# ------------------------------------------------------------------------------------------------
+# zero-initialised scratch (statistic accumulators) and direct gradient accumulation
+# ------------------------------------------------------------------------------------------------
+class ZeroArena:
+    """Bump allocator over one fp32 buffer that is cleared with a single memset per training step.
+
+    Kernels that accumulate with atomics (BatchNorm statistic slots) need zeroed outputs; allocating
+    each with ``torch.zeros`` costs one fill launch apiece (hundreds per step).  Regions handed out
+    since the last :meth:`reset` are zero on first use; ``reset`` (called by the fused optimizer after
+    its step, i.e. once the step's autograd graph is gone) clears the used prefix in one launch.
+    Requests that do not fit fall back to ``torch.zeros``.
+    """
+
+    def __init__(self, capacity_floats: int = 32 * 1024 * 1024):
+        self.capacity = capacity_floats
+        self.buf: Optional[torch.Tensor] = None
+        self.offset = 0
+        self.enabled = True
+
+    def alloc(self, shape, device) -> torch.Tensor:
+        n = 1
+        for s_ in shape:
+            n *= int(s_)
+        n_al = _round_up(max(n, 1), 64)
+        if self.buf is None and self.enabled:
+            self.buf = torch.zeros(self.capacity, dtype=torch.float32, device=device)
+            self.offset = 0
+        if not self.enabled or self.buf.device != torch.device(device) or self.offset + n_al > self.capacity:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.buf[self.offset:self.offset + n].view(shape)
+        self.offset += n_al
+        return out
+
+    def reset(self) -> None:
+        if self.buf is not None and self.offset > 0:
+            self.buf[: self.offset].zero_()
+            self.offset = 0
+
+
+ARENA = ZeroArena()
+
+
+def _grad_sink(param: torch.Tensor, phys_shape) -> Optional[torch.Tensor]:
+    """fp32 buffer to accumulate ``param``'s gradient into directly (its ``.grad`` in physical element order),
+    or ``None`` when the gradient has to be returned to autograd.
+
+    Possible when ``.grad`` already exists with the parameter's dense layout and nothing but this framework's
+    reducer listens for its accumulation (the reducer is then told through ``param._pdt_grad_ready``).
+    """
+    g = param.grad
+    if g is None or g.dtype != torch.float32 or not getattr(param, "_pdt_sink_ok", False) or torch.is_grad_enabled():
+        return None
+    hooks = getattr(param, "_post_accumulate_grad_hooks", None)
+    if hooks and getattr(param, "_pdt_grad_ready", None) is None:
+        return None
+    if g.shape != param.shape or g.stride() != param.stride():
+        return None
+    if param.dim() == 4:
+        view = g.permute(0, 2, 3, 1)
+        if not view.is_contiguous() or tuple(view.shape) != tuple(phys_shape):
+            return None
+        return view
+    if not g.is_contiguous() or tuple(g.shape) != tuple(phys_shape):
+        return None
+    return g
+
+
+def _grad_sunk(param: torch.Tensor) -> None:
+    cb = getattr(param, "_pdt_grad_ready", None)
+    if cb is not None:
+        cb(param)
+
+
+def enable_grad_sink(module: nn.Module) -> int:
+    """Allow convolution / linear weight gradients of ``module`` to be accumulated straight into ``.grad``.
+
+    Only weights that belong to exactly one ``nn.Conv2d`` / ``nn.Linear`` are enabled: a parameter that also
+    receives gradient through another path (tied embeddings, a regulariser) must go through autograd so
+    the contributions are summed before anyone is told the gradient is complete.  Returns the number of
+    parameters enabled.
+    """
+    owners: Dict[int, int] = {}
+    for m in module.modules():
+        for p in m._parameters.values():
+            if p is not None:
+                owners[id(p)] = owners.get(id(p), 0) + 1
+    n = 0
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)) and m.weight is not None and owners.get(id(m.weight), 0) == 1:
+            m.weight._pdt_sink_ok = True
+            n += 1
+    return n
 
 
 # ------------------------------------------------------------------------------------------------
@@ -257,11 +351,31 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
     )
 
 
+import os as _os
+
+WGRAD_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_TARGET_BLOCKS", "640"))
+WGRAD_ATOMIC_CAP_MB = int(_os.environ.get("PDT_WGRAD_ATOMIC_CAP_MB", "8"))
+WGRAD_MIN_BLOCKS = int(_os.environ.get("PDT_WGRAD_MIN_BLOCKS", "384"))
+
+
+def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bt: int) -> int:
+    """How many ways to split the pixel reduction across workgroups.
+
+    More splits fill the chip when the weight tile count is small, but every split adds one fp32 atomic
+    pass over the whole weight gradient (global float atomics run at roughly a quarter of the store rate),
+    so the atomic volume is capped."""
+    tiles = math.ceil(N / bt) * math.ceil(C / bt) * ntaps
+    want = max(1, WGRAD_TARGET_BLOCKS // max(tiles, 1))
+    weight_bytes = 4 * N * C * ntaps
+    cap = max(1, (WGRAD_ATOMIC_CAP_MB << 20) // max(weight_bytes, 1))
+    floor = min(want, math.ceil(WGRAD_MIN_BLOCKS / max(tiles, 1)))
+    return max(1, min(max(min(want, cap), floor), M // 256))
+
+
 def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB) -> None:
     tile = 0 if (N > 64 and C > 64) else 1
     bt = 128 if tile == 0 else 64
-    tiles = math.ceil(N / bt) * math.ceil(C / bt) * len(taps)
-    splits = max(1, min(1024 // max(tiles, 1), M // 512))
+    splits = _wgrad_splits(M, N, C, len(taps), bt)
     dh = _int_array([t[0] for t in taps])
     dwi = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
@@ -293,7 +407,7 @@ class _ConvStats(torch.autograd.Function):
             raise ValueError("output channels must be a multiple of 8")
         y = _empty_nhwc(nb, n, ho, wo, x.device)
         _check_size(y)
-        stats = torch.zeros((STAT_SLOTS, 2, n), dtype=torch.float32, device=x.device) if want_stats else None
+        stats = ARENA.alloc((STAT_SLOTS, 2, n), x.device) if want_stats else None
         ctx.geom = (nb, c, h, w_, n, r, s, ho, wo, stride, padding)
         ctx.col = None
         if c % 64 == 0:
@@ -325,10 +439,14 @@ class _ConvStats(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[1]:
             if ctx.col is None:
-                dwp = torch.zeros((n, r, s, c), dtype=torch.float32, device=dy.device)
+                sink = _grad_sink(weight, (n, r, s, c))
+                dwp = sink if sink is not None else torch.zeros((n, r, s, c), dtype=torch.float32, device=dy.device)
                 taps = [(i - padding, j - padding, (i * s + j) * c) for i in range(r) for j in range(s)]
                 _launch_wgrad(dy, saved, dwp, M, n, n, c, taps, r * s * c, h, w_, stride, ho, wo)
-                dw = dwp.permute(0, 3, 1, 2)
+                if sink is not None:
+                    _grad_sunk(weight)
+                else:
+                    dw = dwp.permute(0, 3, 1, 2)
             else:
                 kpad = ctx.col
                 dwp = torch.zeros((n, kpad), dtype=torch.float32, device=dy.device)
@@ -362,8 +480,8 @@ class _ConvStats(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0):
-    return _ConvStats.apply(x, weight, stride, padding, True)
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True):
+    return _ConvStats.apply(x, weight, stride, padding, want_stats)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -388,13 +506,19 @@ def _bn_consts(stats: Optional[torch.Tensor], bn: nn.BatchNorm2d, count: int, de
     return consts
 
 
-def _bn_backward(dout, out, y, consts, gamma, count, c, y2=None, consts2=None, gamma2=None, want_dz=False):
-    """Shared backward: returns (dy, dgamma, dbeta, extra) where extra = dz | (dy2, dgamma2, dbeta2) | None."""
+def _bn_backward(dout, out, y, consts, gamma, count, c, y2=None, consts2=None, gamma2=None, want_dz=False,
+                 mask_mode=None):
+    """Shared backward: returns (dy, dgamma, dbeta, extra) where extra = dz | (dy2, dgamma2, dbeta2) | None.
+
+    ``mask_mode``: 0 no ReLU, 1 ReLU mask from the stored output, 2 ReLU mask recomputed from ``y`` (plain
+    BN+ReLU: saves reading the output tensor in both passes)."""
     dev = y.device
     M = y.numel() // c
-    slots = torch.zeros((STAT_SLOTS, 3, c), dtype=torch.float32, device=dev)
+    if mask_mode is None:
+        mask_mode = 1 if out is not None else 0
+    slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
     _check(_bn_bwd_reduce(dout.data_ptr(), _ptr(out), y.data_ptr(), consts.data_ptr(), _ptr(y2), _ptr(consts2),
-                          slots.data_ptr(), M, c, _stream()), "bn_bwd_reduce")
+                          slots.data_ptr(), M, c, mask_mode, _stream()), "bn_bwd_reduce")
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     coef = torch.empty((3, c), dtype=torch.float32, device=dev)
@@ -414,8 +538,8 @@ def _bn_backward(dout, out, y, consts, gamma, count, c, y2=None, consts2=None, g
     elif want_dz:
         dz = torch.empty_like(y)
         extra = dz
-    _check(_bn_bwd_apply(dout.data_ptr(), _ptr(out), y.data_ptr(), coef.data_ptr(), dy.data_ptr(), _ptr(dz), _ptr(y2),
-                         _ptr(coef2), _ptr(dy2), y.numel(), c, _stream()), "bn_bwd_apply")
+    _check(_bn_bwd_apply(dout.data_ptr(), _ptr(out), y.data_ptr(), coef.data_ptr(), consts.data_ptr(), dy.data_ptr(),
+                         _ptr(dz), _ptr(y2), _ptr(coef2), _ptr(dy2), y.numel(), c, mask_mode, _stream()), "bn_bwd_apply")
     return dy, dgamma, dbeta, extra
 
 
@@ -429,16 +553,16 @@ class _BnAct(torch.autograd.Function):
         out = torch.empty_like(y)
         _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), None, None, out.data_ptr(), y.numel(), c, int(relu),
                              _stream()), "bn_apply_fwd")
-        ctx.save_for_backward(y, out if relu else None, consts, gamma)
+        ctx.save_for_backward(y, consts, gamma)
         ctx.meta = (count, c, relu)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, out, consts, gamma = ctx.saved_tensors
+        y, consts, gamma = ctx.saved_tensors
         count, c, relu = ctx.meta
         dout = _as_nhwc(dout)
-        dy, dgamma, dbeta, _ = _bn_backward(dout, out, y, consts, gamma, count, c)
+        dy, dgamma, dbeta, _ = _bn_backward(dout, None, y, consts, gamma, count, c, mask_mode=2 if relu else 0)
         return dy, None, dgamma, dbeta, None, None
 
 
@@ -497,7 +621,7 @@ class _BnReluMaxpool(torch.autograd.Function):
         dout = _as_nhwc(dout)
         dev = y.device
         dz = torch.empty_like(y)
-        slots = torch.zeros((STAT_SLOTS, 3, c), dtype=torch.float32, device=dev)
+        slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
         _check(_maxpool_bn_bwd_reduce(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), dz.data_ptr(),
                                       slots.data_ptr(), nb, h, w, c, _stream()), "maxpool_bn_bwd_reduce")
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
@@ -506,8 +630,8 @@ class _BnReluMaxpool(torch.autograd.Function):
         _check(_bn_bwd_finalize(slots.data_ptr(), c, 1, float(count), _ptr(gamma), consts.data_ptr(), dgamma.data_ptr(),
                                 dbeta.data_ptr(), coef.data_ptr(), _stream()), "bn_bwd_finalize")
         dy = torch.empty_like(y)
-        _check(_bn_bwd_apply(dz.data_ptr(), None, y.data_ptr(), coef.data_ptr(), dy.data_ptr(), None, None, None, None,
-                             y.numel(), c, _stream()), "bn_bwd_apply")
+        _check(_bn_bwd_apply(dz.data_ptr(), None, y.data_ptr(), coef.data_ptr(), consts.data_ptr(), dy.data_ptr(), None,
+                             None, None, None, y.numel(), c, 0, _stream()), "bn_bwd_apply")
         return dy, None, dgamma, dbeta, None
 
 
@@ -517,7 +641,7 @@ def bn_act(y, stats, bn, relu: bool = True):
 
 def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
     a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True)
-    return _ConvStats.apply(a, weight, stride, padding, True)
+    return _ConvStats.apply(a, weight, stride, padding, bn.training)
 
 
 def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
@@ -607,8 +731,12 @@ class _Linear(torch.autograd.Function):
             _launch_gather_gemm(gp, wt, dx, None, None, M, k, npad, k, npad, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
             dx = dx.reshape(*lead, k)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((n, k), dtype=torch.float32, device=g.device)
+            sink = _grad_sink(weight, (n, k))
+            dw = sink if sink is not None else torch.zeros((n, k), dtype=torch.float32, device=g.device)
             _launch_wgrad(gp, x2, dw, M, n, npad, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1)
+            if sink is not None:
+                _grad_sunk(weight)
+                dw = None
         if has_bias and ctx.needs_input_grad[2]:
             db = gp[:, :n].sum(dim=0, dtype=torch.float32)
         return dx, dw, db
@@ -741,6 +869,7 @@ def multi_tensor_step(plan: MultiTensorPlan, group) -> None:
     SHADOWS.epoch += 1
     for p in plan.shadow_params:
         SHADOWS.mark_refreshed(p)
+    ARENA.reset()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -112,7 +112,11 @@ class GradReducer:
         self._index: Dict[int, int] = {id(p): i for i, p in enumerate(self.params)}
         self._build(order=None)
         for i, p in enumerate(self.params):
-            self._hook_handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            hook = self._make_hook(i)
+            self._hook_handles.append(p.register_post_accumulate_grad_hook(hook))
+            # kernels that accumulate a gradient straight into ``p.grad`` (bypassing autograd's
+            # accumulation, so the hook above does not fire) report through this attribute instead
+            p._pdt_grad_ready = hook
 
     # ------------------------------------------------------------------ construction
     def _build(self, order: Optional[Sequence[int]]) -> None:
@@ -166,7 +170,12 @@ class GradReducer:
             self._armed = True
             self._lib.pdt_reducer_prepare(self._h)
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
-        self._lib.pdt_reducer_mark_ready(self._h, index)
+        if self._lib.pdt_reducer_mark_ready(self._h, index) < 0:
+            raise RuntimeError(
+                f"parameter #{index} reported a complete gradient twice in one backward pass: it receives "
+                "gradient through more than one path, so it must not be accumulated directly by a kernel "
+                "(see ops.hip.enable_grad_sink)"
+            )
 
     def _finalize(self) -> None:
         self.unused_last = self._lib.pdt_reducer_finalize(self._h)
@@ -231,6 +240,9 @@ class GradReducer:
         for h in self._hook_handles:
             h.remove()
         self._hook_handles.clear()
+        for p in self.params:
+            if hasattr(p, "_pdt_grad_ready"):
+                del p._pdt_grad_ready
         if self._h:
             self._lib.pdt_reducer_destroy(self._h)
             self._h = None

@@ -143,7 +143,7 @@ class Trainer:
         model = model.to(self.device)
         if self.device.type == "cuda":
             model = model.to(memory_format=torch.channels_last)
-        self.raw_model = model
+        self.raw_model = ops.prepare_module(model)
         if self.env.distributed:
             model = wrap_data_parallel(
                 model, self.env, cfg.bucket_mb, cfg.first_bucket_mb, cfg.sync_buffers, cfg.native_rccl
