@@ -94,6 +94,7 @@ def main():
             saved_tensors = (x.detach(), w)
             geom = (args.batch, cin, hw, hw, cout, k, k, ho, ho, stride, pad)
             col = None
+            link = None
             needs_input_grad = (False, False, False, False, False)
 
         def dgrad():

@@ -238,7 +238,8 @@ PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, 
 // ------------------------------------------------------------------------------------------------
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ slots, int C, int which, float count,
                                        const float* __restrict__ gamma, const float* __restrict__ consts,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                       int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sdz = 0.f, sdzx = 0.f;
@@ -248,8 +249,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ slots, int C, i
     }
     const float mean = consts[c], rstd = consts[C + c];
     const float g = gamma != nullptr ? gamma[c] : 1.f;
-    if (dgamma != nullptr) dgamma[c] = sdzx;
-    if (dbeta != nullptr) dbeta[c] = sdz;
+    if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + sdzx : sdzx;
+    if (dbeta != nullptr) dbeta[c] = accumulate ? dbeta[c] + sdz : sdz;
     const float k1 = g * rstd;
     const float b = -k1 * rstd * sdzx / count;
     coef[c] = k1;
@@ -257,11 +258,13 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ slots, int C, i
     coef[2 * C + c] = -k1 * sdz / count - b * mean;
 }
 
+// accumulate != 0: dgamma / dbeta are added to (gradient buffers that already hold a value).
 PDT_API int pdt_bn_bwd_finalize(const float* slots, int C, int which, float count, const float* gamma,
-                                const float* consts, float* dgamma, float* dbeta, float* coef, void* stream) {
+                                const float* consts, float* dgamma, float* dbeta, float* coef, int accumulate,
+                                void* stream) {
     if (C <= 0 || (which != 1 && which != 2)) return -1;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pdt_cdiv(C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), slots, C,
-                       which, count, gamma, consts, dgamma, dbeta, coef);
+                       which, count, gamma, consts, dgamma, dbeta, coef, accumulate);
     return pdt_launch_status();
 }
 

@@ -33,6 +33,7 @@ struct GatherGemmArgs {
     bf16* Out;
     float* stats;       // [PDT_STAT_SLOTS][2][N] zero-initialised (sum, sumsq) accumulators, or nullptr
     const float* bias;  // [N] or nullptr
+    const bf16* addend; // tensor with the layout of Out added to the result (residual gradient), or nullptr
     int M, N, ldb, ldo, C, T;
     int Hin, Win, istr;
     int Hout, Wout, ostr, oph, opw;
@@ -207,12 +208,17 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
         const int row = prow + ps * RPP;
         const int m = m0 + row;
         if (m < p.M && ncol < p.N) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
             const uint32_t img = fastdiv(m, p.div_ab);
             const uint32_t rem = m - img * (p.OA * p.OB);
             const uint32_t a = fastdiv(rem, p.div_b);
             const uint32_t b = rem - a * p.OB;
             const size_t pix = (static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw;
+            if (p.addend != nullptr) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(p.addend + pix * p.ldo + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) + bf16_to_f32(av[e]));
+            }
             *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -259,7 +265,8 @@ static int launch_gather_gemm(const GatherGemmArgs& a, hipStream_t stream) {
 // Host entry.  Shapes are validated here; the kernel assumes them.
 //   tile: 0 = 128x128, 1 = 128x64 (narrow N), 2 = 256x128... (see switch)
 // Returns 0 on success, -1 on invalid arguments, otherwise a hipError_t.
-PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stats, const float* bias, int M, int N,
+PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stats, const float* bias,
+                            const void* addend, int M, int N,
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
                             const int* tap_woff, int tile, void* stream) {
@@ -271,6 +278,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.Out = static_cast<bf16*>(Out);
     a.stats = stats;
     a.bias = bias;
+    a.addend = static_cast<const bf16*>(addend);
     a.M = M; a.N = N; a.ldb = ldb; a.ldo = ldo; a.C = C; a.T = T;
     a.Hin = Hin; a.Win = Win; a.istr = istr;
     a.Hout = Hout; a.Wout = Wout; a.ostr = ostr; a.oph = oph; a.opw = opw;

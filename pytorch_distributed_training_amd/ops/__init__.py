@@ -22,12 +22,19 @@ def _hip():
     return hip
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True):
+def residual_link(x):
+    """Token shared by the first convolution of a residual block and the block tail (both consume the block
+    input ``x``): on GPU it lets the shortcut gradient be added inside the convolution's data-gradient kernel
+    instead of in a separate pass.  ``None`` (no effect) for CPU tensors."""
+    return _hip().residual_link() if x.is_cuda else None
+
+
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None):
     """Convolution without bias.  Returns ``(y, stats)`` where ``stats`` carries the per-channel
     batch statistics of ``y`` gathered in the kernel epilogue (``None`` on CPU or when not wanted,
     e.g. in inference where BatchNorm uses its running statistics)."""
     if x.is_cuda:
-        return _hip().conv2d_stats(x, weight, stride, padding, want_stats)
+        return _hip().conv2d_stats(x, weight, stride, padding, want_stats, link)
     return _ref.conv2d_stats(x, weight, stride, padding)
 
 
@@ -45,10 +52,10 @@ def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int
     return _ref.bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride, padding)
 
 
-def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
+def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):
     """relu(bn(y) + identity), or relu(bn(y) + id_bn(identity)) for a projected shortcut."""
     if y.is_cuda:
-        return _hip().bn_add_relu(y, stats, bn, identity, id_stats, id_bn)
+        return _hip().bn_add_relu(y, stats, bn, identity, id_stats, id_bn, link)
     return _ref.bn_add_relu(y, stats, bn, identity, id_stats, id_bn)
 
 

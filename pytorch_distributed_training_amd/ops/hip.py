@@ -40,12 +40,12 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
-_bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp])
+_bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 _bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_relu_maxpool_fwd = _sig("pdt_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _maxpool_bn_bwd_reduce = _sig("pdt_maxpool_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
@@ -180,6 +180,10 @@ def enable_grad_sink(module: nn.Module) -> int:
         if isinstance(m, (nn.Conv2d, nn.Linear)) and m.weight is not None and owners.get(id(m.weight), 0) == 1:
             m.weight._pdt_sink_ok = True
             n += 1
+        elif isinstance(m, nn.BatchNorm2d) and m.weight is not None and m.bias is not None:
+            if owners.get(id(m.weight), 0) == 1 and owners.get(id(m.bias), 0) == 1:
+                m.weight._pdt_sink_ok = m.bias._pdt_sink_ok = True
+                n += 2
     return n
 
 
@@ -340,12 +344,12 @@ def _pick_tile(m: int, n: int) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw) -> None:
+                        oph, opw, addend=None) -> None:
     dh = _int_array([t[0] for t in taps])
     dw = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
     _check(
-        _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), M, N, ldb, ldo, C, len(taps),
+        _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), M, N, ldb, ldo, C, len(taps),
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), _stream()),
         "gather_gemm",
     )
@@ -390,11 +394,23 @@ def _conv_out(h: int, k: int, s: int, p: int) -> int:
     return (h + 2 * p - k) // s + 1
 
 
+class ResidualLink:
+    """Carries the shortcut gradient of a residual block from the block-tail backward to the data-gradient
+    kernel of the block's first convolution, which adds it in its epilogue.  Both consume the same block
+    input ``x``; without the link autograd would materialise both gradients and add them in a separate pass."""
+
+    __slots__ = ("grad", "armed")
+
+    def __init__(self):
+        self.grad = None
+        self.armed = False  # set in forward by the convolution that will consume the gradient
+
+
 class _ConvStats(torch.autograd.Function):
     """y = conv2d(x, w) (no bias) and per-channel statistic accumulators of y."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, padding: int, want_stats: bool):
+    def forward(ctx, x, weight, stride: int, padding: int, want_stats: bool, link: Optional[ResidualLink] = None):
         x = _as_nhwc(x)
         nb, c, h, w_ = x.shape
         n, c2, r, s = weight.shape
@@ -410,6 +426,11 @@ class _ConvStats(torch.autograd.Function):
         stats = ARENA.alloc((STAT_SLOTS, 2, n), x.device) if want_stats else None
         ctx.geom = (nb, c, h, w_, n, r, s, ho, wo, stride, padding)
         ctx.col = None
+        ctx.link = None
+        ctx.set_materialize_grads(False)  # the statistics output never carries a gradient: do not zero-fill one
+        if link is not None and c % 64 == 0 and stride == 1 and ctx.needs_input_grad[0]:
+            link.armed = True
+            ctx.link = link
         if c % 64 == 0:
             wb = SHADOWS.fwd(weight)
             taps = [(i - padding, j - padding, (i * s + j) * c) for i in range(r) for j in range(s)]
@@ -434,6 +455,8 @@ class _ConvStats(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         saved, weight = ctx.saved_tensors
         nb, c, h, w_, n, r, s, ho, wo, stride, padding = ctx.geom
+        if dy is None:
+            return None, None, None, None, None, None
         dy = _as_nhwc(dy)
         M = nb * ho * wo
         dx = dw = None
@@ -459,6 +482,11 @@ class _ConvStats(torch.autograd.Function):
             if npad != n:
                 raise NotImplementedError("data gradient needs Cout % 64 == 0")
             dx = _empty_nhwc(nb, c, h, w_, dy.device)
+            addend = None
+            if ctx.link is not None and ctx.link.grad is not None:
+                addend, ctx.link.grad = _as_nhwc(ctx.link.grad), None
+                if addend.shape != dx.shape:
+                    raise RuntimeError("residual link carries a gradient of the wrong shape")
             for ph in range(stride):
                 oa = (h - ph + stride - 1) // stride
                 if oa <= 0:
@@ -476,12 +504,18 @@ class _ConvStats(torch.autograd.Function):
                                 continue
                             taps.append(((ph + padding - i) // stride, (pw + padding - j) // stride, (i * s + j) * npad))
                     _launch_gather_gemm(dy, wt, dx, None, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
-                                        oa, ob, h, w_, stride, ph, pw)
-        return dx, dw, None, None, None
+                                        oa, ob, h, w_, stride, ph, pw, addend)
+        elif ctx.link is not None and ctx.link.grad is not None:
+            raise RuntimeError("residual link armed but the convolution input needs no gradient")
+        return dx, dw, None, None, None, None
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True):
-    return _ConvStats.apply(x, weight, stride, padding, want_stats)
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None):
+    return _ConvStats.apply(x, weight, stride, padding, want_stats, link)
+
+
+def residual_link():
+    return ResidualLink()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -506,8 +540,27 @@ def _bn_consts(stats: Optional[torch.Tensor], bn: nn.BatchNorm2d, count: int, de
     return consts
 
 
-def _bn_backward(dout, out, y, consts, gamma, count, c, y2=None, consts2=None, gamma2=None, want_dz=False,
-                 mask_mode=None):
+def _bn_param_grads(slots, which, count, gamma, beta, consts, c, dev):
+    """Runs bn_bwd_finalize; dgamma / dbeta go straight into ``gamma.grad`` / ``beta.grad`` when allowed.
+    Returns (dgamma | None, dbeta | None, coef)."""
+    coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+    sg = _grad_sink(gamma, (c,)) if gamma is not None else None
+    sb = _grad_sink(beta, (c,)) if beta is not None else None
+    if sg is not None and sb is not None:
+        _check(_bn_bwd_finalize(slots.data_ptr(), c, which, float(count), _ptr(gamma), consts.data_ptr(), sg.data_ptr(),
+                                sb.data_ptr(), coef.data_ptr(), 1, _stream()), "bn_bwd_finalize")
+        _grad_sunk(gamma)
+        _grad_sunk(beta)
+        return None, None, coef
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    _check(_bn_bwd_finalize(slots.data_ptr(), c, which, float(count), _ptr(gamma), consts.data_ptr(), dgamma.data_ptr(),
+                            dbeta.data_ptr(), coef.data_ptr(), 0, _stream()), "bn_bwd_finalize")
+    return dgamma, dbeta, coef
+
+
+def _bn_backward(dout, out, y, consts, gamma, beta, count, c, y2=None, consts2=None, gamma2=None, beta2=None,
+                 want_dz=False, mask_mode=None):
     """Shared backward: returns (dy, dgamma, dbeta, extra) where extra = dz | (dy2, dgamma2, dbeta2) | None.
 
     ``mask_mode``: 0 no ReLU, 1 ReLU mask from the stored output, 2 ReLU mask recomputed from ``y`` (plain
@@ -519,20 +572,12 @@ def _bn_backward(dout, out, y, consts, gamma, count, c, y2=None, consts2=None, g
     slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
     _check(_bn_bwd_reduce(dout.data_ptr(), _ptr(out), y.data_ptr(), consts.data_ptr(), _ptr(y2), _ptr(consts2),
                           slots.data_ptr(), M, c, mask_mode, _stream()), "bn_bwd_reduce")
-    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    coef = torch.empty((3, c), dtype=torch.float32, device=dev)
-    _check(_bn_bwd_finalize(slots.data_ptr(), c, 1, float(count), _ptr(gamma), consts.data_ptr(), dgamma.data_ptr(),
-                            dbeta.data_ptr(), coef.data_ptr(), _stream()), "bn_bwd_finalize")
+    dgamma, dbeta, coef = _bn_param_grads(slots, 1, count, gamma, beta, consts, c, dev)
     dy = torch.empty_like(y)
     extra = None
     dz = dy2 = coef2 = None
     if y2 is not None:
-        dgamma2 = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta2 = torch.empty(c, dtype=torch.float32, device=dev)
-        coef2 = torch.empty((3, c), dtype=torch.float32, device=dev)
-        _check(_bn_bwd_finalize(slots.data_ptr(), c, 2, float(count), _ptr(gamma2), consts2.data_ptr(),
-                                dgamma2.data_ptr(), dbeta2.data_ptr(), coef2.data_ptr(), _stream()), "bn_bwd_finalize")
+        dgamma2, dbeta2, coef2 = _bn_param_grads(slots, 2, count, gamma2, beta2, consts2, c, dev)
         dy2 = torch.empty_like(y2)
         extra = (dy2, dgamma2, dbeta2)
     elif want_dz:
@@ -553,22 +598,22 @@ class _BnAct(torch.autograd.Function):
         out = torch.empty_like(y)
         _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), None, None, out.data_ptr(), y.numel(), c, int(relu),
                              _stream()), "bn_apply_fwd")
-        ctx.save_for_backward(y, consts, gamma)
+        ctx.save_for_backward(y, consts, gamma, beta)
         ctx.meta = (count, c, relu)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, consts, gamma = ctx.saved_tensors
+        y, consts, gamma, beta = ctx.saved_tensors
         count, c, relu = ctx.meta
         dout = _as_nhwc(dout)
-        dy, dgamma, dbeta, _ = _bn_backward(dout, None, y, consts, gamma, count, c, mask_mode=2 if relu else 0)
+        dy, dgamma, dbeta, _ = _bn_backward(dout, None, y, consts, gamma, beta, count, c, mask_mode=2 if relu else 0)
         return dy, None, dgamma, dbeta, None, None
 
 
 class _BnAddRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, bn, ident, id_stats, id_gamma, id_beta, id_bn):
+    def forward(ctx, y, stats, gamma, beta, bn, ident, id_stats, id_gamma, id_beta, id_bn, link=None):
         y = _as_nhwc(y)
         ident = _as_nhwc(ident)
         if ident.shape != y.shape:
@@ -581,21 +626,25 @@ class _BnAddRelu(torch.autograd.Function):
         _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), ident.data_ptr(), _ptr(iconsts), out.data_ptr(), y.numel(),
                              c, 1, _stream()), "bn_apply_fwd")
         ctx.projected = id_bn is not None
-        ctx.save_for_backward(y, out, consts, gamma, ident if ctx.projected else None, iconsts, id_gamma)
+        ctx.link = link if (link is not None and link.armed and not ctx.projected) else None
+        ctx.save_for_backward(y, out, consts, gamma, beta, ident if ctx.projected else None, iconsts, id_gamma, id_beta)
         ctx.meta = (count, c)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, out, consts, gamma, ident, iconsts, id_gamma = ctx.saved_tensors
+        y, out, consts, gamma, beta, ident, iconsts, id_gamma, id_beta = ctx.saved_tensors
         count, c = ctx.meta
         dout = _as_nhwc(dout)
         if ctx.projected:
-            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, out, y, consts, gamma, count, c, ident,
-                                                                      iconsts, id_gamma)
-            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None
-        dy, dgamma, dbeta, dz = _bn_backward(dout, out, y, consts, gamma, count, c, want_dz=True)
-        return dy, None, dgamma, dbeta, None, dz, None, None, None, None
+            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, out, y, consts, gamma, beta, count, c, ident,
+                                                                      iconsts, id_gamma, id_beta)
+            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None, None
+        dy, dgamma, dbeta, dz = _bn_backward(dout, out, y, consts, gamma, beta, count, c, want_dz=True)
+        if ctx.link is not None:
+            ctx.link.grad = dz  # added to the first convolution's data gradient in that kernel's epilogue
+            dz = None
+        return dy, None, dgamma, dbeta, None, dz, None, None, None, None, None
 
 
 class _BnReluMaxpool(torch.autograd.Function):
@@ -610,13 +659,13 @@ class _BnReluMaxpool(torch.autograd.Function):
         idx = torch.empty((nb, ho, wo, c), dtype=torch.uint8, device=y.device)
         _check(_bn_relu_maxpool_fwd(y.data_ptr(), consts.data_ptr(), out.data_ptr(), idx.data_ptr(), nb, h, w, c,
                                     _stream()), "bn_relu_maxpool_fwd")
-        ctx.save_for_backward(y, idx, consts, gamma)
+        ctx.save_for_backward(y, idx, consts, gamma, beta)
         ctx.meta = (count, c, nb, h, w)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, idx, consts, gamma = ctx.saved_tensors
+        y, idx, consts, gamma, beta = ctx.saved_tensors
         count, c, nb, h, w = ctx.meta
         dout = _as_nhwc(dout)
         dev = y.device
@@ -624,11 +673,7 @@ class _BnReluMaxpool(torch.autograd.Function):
         slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
         _check(_maxpool_bn_bwd_reduce(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), dz.data_ptr(),
                                       slots.data_ptr(), nb, h, w, c, _stream()), "maxpool_bn_bwd_reduce")
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-        coef = torch.empty((3, c), dtype=torch.float32, device=dev)
-        _check(_bn_bwd_finalize(slots.data_ptr(), c, 1, float(count), _ptr(gamma), consts.data_ptr(), dgamma.data_ptr(),
-                                dbeta.data_ptr(), coef.data_ptr(), _stream()), "bn_bwd_finalize")
+        dgamma, dbeta, coef = _bn_param_grads(slots, 1, count, gamma, beta, consts, c, dev)
         dy = torch.empty_like(y)
         _check(_bn_bwd_apply(dz.data_ptr(), None, y.data_ptr(), coef.data_ptr(), consts.data_ptr(), dy.data_ptr(), None,
                              None, None, None, y.numel(), c, 0, _stream()), "bn_bwd_apply")
@@ -644,10 +689,10 @@ def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int
     return _ConvStats.apply(a, weight, stride, padding, bn.training)
 
 
-def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
+def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):
     if id_bn is not None:
-        return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn)
-    return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None)
+        return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn, None)
+    return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None, link)
 
 
 def bn_relu_maxpool(y, stats, bn):

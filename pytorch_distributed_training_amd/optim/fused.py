@@ -43,6 +43,7 @@ class FusedOptimizer(Optimizer):
                         momentum=momentum, grad_scale=grad_scale)
         super().__init__(params, defaults)
         self._plans: Dict[int, object] = {}  # per param-group GPU launch plans
+        self._flat_grads: Dict[int, tuple] = {}  # per param-group (flat gradient buffer, view pointers)
 
     # ------------------------------------------------------------------ state
     def _init_state(self, group) -> None:
@@ -132,8 +133,45 @@ class FusedOptimizer(Optimizer):
         hip.multi_tensor_step(plan, group)
 
     def zero_grad(self, set_to_none: bool = False) -> None:
-        """Gradients that are views of reducer buckets must stay in place, so the default here is zeroing."""
-        super().zero_grad(set_to_none=set_to_none)
+        """Zero the gradients in place (the default keeps ``.grad`` allocated: kernels accumulate into it).
+
+        On GPU the gradients of a group are re-homed, once, as views of one flat buffer, so clearing them is a
+        single memset instead of one fill launch per tensor.  Parameters managed by a gradient reducer already
+        live in its buckets and are left alone (use the reducer's ``zero_grad``)."""
+        if set_to_none:
+            self._flat_grads.clear()
+            super().zero_grad(set_to_none=True)
+            return
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.requires_grad]
+            if not params:
+                continue
+            if not params[0].is_cuda or any(hasattr(p, "_pdt_grad_ready") for p in params):
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.zero_()
+                continue
+            flat = self._flat_grads.get(gi)
+            if flat is None or any(p.grad is None or p.grad.data_ptr() != ptr for p, ptr in zip(params, flat[1])):
+                flat = self._build_flat_grads(params)
+                self._flat_grads[gi] = flat
+            flat[0].zero_()
+
+    @staticmethod
+    def _build_flat_grads(params: List[torch.Tensor]):
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        buf = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        ptrs = []
+        for p, off in zip(params, offs):
+            view = torch.as_strided(buf, p.shape, p.stride(), off) if p.numel() else buf[off:off].view(p.shape)
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view
+            ptrs.append(view.data_ptr())
+        return buf, ptrs
 
 
 def build_optimizer(params, name: str, lr: float, weight_decay: float, momentum: float = 0.9,

@@ -288,3 +288,37 @@ def test_resnet18_matches_reference_model_and_learns():
         opt.step()
         losses.append(float(l))
     assert losses[-1] < 0.6 * losses[0]
+
+
+def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypatch):
+    """The shortcut gradient added in the dgrad epilogue equals the one autograd would add in a separate pass."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models.resnet import Bottleneck
+
+    torch.manual_seed(7)
+    dev = _dev()
+    blk = Bottleneck(256, 64).to(dev).to(memory_format=torch.channels_last)
+    x0 = hip.to_device_layout(torch.randn(4, 256, 14, 14, device=dev))
+    g = hip.to_device_layout(torch.randn(4, 256, 14, 14, device=dev))
+    links = []
+    real_link = ops.residual_link
+
+    def spy(x):
+        l = real_link(x)
+        links.append(l)
+        return l
+
+    monkeypatch.setattr(ops, "residual_link", spy)
+    xa = x0.clone().requires_grad_(True)
+    blk(xa).backward(g)
+    assert len(links) == 1 and links[0].armed and links[0].grad is None  # produced and consumed
+    wa = blk.conv1.weight.grad.clone()
+    blk.zero_grad(set_to_none=True)
+    monkeypatch.setattr(ops, "residual_link", lambda x: None)
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.reset_running_stats()
+    xb = x0.clone().requires_grad_(True)
+    blk(xb).backward(g)
+    assert _rel_err(xa.grad, xb.grad) < 4e-3  # one bf16 rounding apart (sum rounded once vs twice)
+    assert _rel_err(wa, blk.conv1.weight.grad) < 1e-6
