@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
     constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
     static_assert(WM * WN == 4, "four waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sA = reinterpret_cast<bf16*>(smem);  // [2][BM][64]
-    bf16* sB = sA + 2 * BM * GG_BK;            // [2][BN][64]
+    // staging buffers: [stage][A tile BM x 64 | B tile BN x 64]; a single-step launch touches stage 0 only
+    constexpr int STAGE = (BM + BN) * GG_BK;
+    bf16* sA = reinterpret_cast<bf16*>(smem);
+    bf16* sB = sA + BM * GG_BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -120,12 +122,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int row = lrow + 32 * i;
-            *reinterpret_cast<bf16x8*>(sA + (buf * BM + row) * GG_BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
+            *reinterpret_cast<bf16x8*>(sA + buf * STAGE + row * GG_BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int row = lrow + 32 * i;
-            *reinterpret_cast<bf16x8*>(sB + (buf * BN + row) * GG_BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
+            *reinterpret_cast<bf16x8*>(sB + buf * STAGE + row * GG_BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
         }
     };
     auto compute = [&](int buf) {
@@ -136,12 +138,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int row = wm * TM + i * 16 + (lane & 15);
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + (buf * BM + row) * GG_BK + ((kc ^ (row & 7)) << 3));
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + buf * STAGE + row * GG_BK + ((kc ^ (row & 7)) << 3));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int row = wn * TN + j * 16 + (lane & 15);
-                fb[j] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + row) * GG_BK + ((kc ^ (row & 7)) << 3));
+                fb[j] = *reinterpret_cast<const bf16x8*>(sB + buf * STAGE + row * GG_BK + ((kc ^ (row & 7)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -256,8 +258,13 @@ static int launch_gather_gemm(const GatherGemmArgs& a, hipStream_t stream) {
     constexpr size_t lds_loop = 2ull * (BM + BN) * GG_BK * sizeof(bf16);
     constexpr size_t lds_epi = static_cast<size_t>(BM) * (BN + 8) * sizeof(bf16);
     constexpr size_t lds_stats = (256 / (BN / 8)) * 2ull * BN * sizeof(float);
-    constexpr size_t lds = lds_loop > lds_epi ? (lds_loop > lds_stats ? lds_loop : lds_stats)
-                                              : (lds_epi > lds_stats ? lds_epi : lds_stats);
+    constexpr size_t lds_full = lds_loop > lds_epi ? (lds_loop > lds_stats ? lds_loop : lds_stats)
+                                                   : (lds_epi > lds_stats ? lds_epi : lds_stats);
+    // A single K-step touches only the first staging buffer: request half the loop LDS so twice as many
+    // workgroups are resident (these launches are bound by their loads and stores, not by MFMA).
+    constexpr size_t lds_half = (lds_loop / 2) > lds_epi ? ((lds_loop / 2) > lds_stats ? lds_loop / 2 : lds_stats)
+                                                         : (lds_epi > lds_stats ? lds_epi : lds_stats);
+    const size_t lds = (a.T * (a.C / GG_BK) <= 1) ? lds_half : lds_full;
     hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, stream, a);
     return pdt_launch_status();
 }

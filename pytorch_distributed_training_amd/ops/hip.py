@@ -135,14 +135,13 @@ def _grad_sink(param: torch.Tensor, phys_shape) -> Optional[torch.Tensor]:
     """fp32 buffer to accumulate ``param``'s gradient into directly (its ``.grad`` in physical element order),
     or ``None`` when the gradient has to be returned to autograd.
 
-    Possible when ``.grad`` already exists with the parameter's dense layout and nothing but this framework's
-    reducer listens for its accumulation (the reducer is then told through ``param._pdt_grad_ready``).
+    Possible when ``.grad`` already exists with the parameter's dense layout and the parameter was whitelisted
+    by :func:`enable_grad_sink`.  The backward then returns ``None`` for the parameter; autograd still runs its
+    AccumulateGrad node (adding contributions from other paths, if any) and fires post-accumulate hooks, so
+    gradient reducers are notified exactly as for ordinary gradients.
     """
     g = param.grad
     if g is None or g.dtype != torch.float32 or not getattr(param, "_pdt_sink_ok", False) or torch.is_grad_enabled():
-        return None
-    hooks = getattr(param, "_post_accumulate_grad_hooks", None)
-    if hooks and getattr(param, "_pdt_grad_ready", None) is None:
         return None
     if g.shape != param.shape or g.stride() != param.stride():
         return None
@@ -154,12 +153,6 @@ def _grad_sink(param: torch.Tensor, phys_shape) -> Optional[torch.Tensor]:
     if not g.is_contiguous() or tuple(g.shape) != tuple(phys_shape):
         return None
     return g
-
-
-def _grad_sunk(param: torch.Tensor) -> None:
-    cb = getattr(param, "_pdt_grad_ready", None)
-    if cb is not None:
-        cb(param)
 
 
 def enable_grad_sink(module: nn.Module) -> int:
@@ -466,9 +459,7 @@ class _ConvStats(torch.autograd.Function):
                 dwp = sink if sink is not None else torch.zeros((n, r, s, c), dtype=torch.float32, device=dy.device)
                 taps = [(i - padding, j - padding, (i * s + j) * c) for i in range(r) for j in range(s)]
                 _launch_wgrad(dy, saved, dwp, M, n, n, c, taps, r * s * c, h, w_, stride, ho, wo)
-                if sink is not None:
-                    _grad_sunk(weight)
-                else:
+                if sink is None:
                     dw = dwp.permute(0, 3, 1, 2)
             else:
                 kpad = ctx.col
@@ -549,8 +540,6 @@ def _bn_param_grads(slots, which, count, gamma, beta, consts, c, dev):
     if sg is not None and sb is not None:
         _check(_bn_bwd_finalize(slots.data_ptr(), c, which, float(count), _ptr(gamma), consts.data_ptr(), sg.data_ptr(),
                                 sb.data_ptr(), coef.data_ptr(), 1, _stream()), "bn_bwd_finalize")
-        _grad_sunk(gamma)
-        _grad_sunk(beta)
         return None, None, coef
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
@@ -780,7 +769,6 @@ class _Linear(torch.autograd.Function):
             dw = sink if sink is not None else torch.zeros((n, k), dtype=torch.float32, device=g.device)
             _launch_wgrad(gp, x2, dw, M, n, npad, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1)
             if sink is not None:
-                _grad_sunk(weight)
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
             db = gp[:, :n].sum(dim=0, dtype=torch.float32)

@@ -146,7 +146,7 @@ class FusedOptimizer(Optimizer):
             params = [p for p in group["params"] if p.requires_grad]
             if not params:
                 continue
-            if not params[0].is_cuda or any(hasattr(p, "_pdt_grad_ready") for p in params):
+            if not params[0].is_cuda or any(hasattr(p, "_pdt_bucket_view") for p in params):
                 for p in params:
                     if p.grad is not None:
                         p.grad.zero_()

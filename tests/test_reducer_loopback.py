@@ -206,3 +206,27 @@ def test_wrapper_broadcasts_initial_state_and_strips_prefix():
     ref = _mlp(seed=0).state_dict()
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]) and torch.equal(sd0[k], ref[k])
+
+
+def test_post_accumulate_hook_fires_for_undefined_gradient():
+    """Kernels may accumulate a weight gradient straight into ``.grad`` and return None from backward; the
+    reducer relies on autograd still firing the post-accumulate hook for that parameter."""
+
+    class SinkFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.w.grad.add_(1.0)  # "kernel" wrote the gradient itself
+            return g * 2, None
+
+    fab = LoopbackFabric(1)
+    w = nn.Parameter(torch.ones(3))
+    red = GradReducer([w], LoopbackTransport(fab, 0))
+    x = torch.ones(3, requires_grad=True)
+    SinkFn.apply(x, w).sum().backward()
+    assert red.iterations == 1 and red.unused_last == 0
+    assert torch.equal(w.grad, torch.ones(3))
