@@ -268,8 +268,10 @@ class RcclTransport(Transport):
             raise RuntimeError(f"RCCL bucket all-reduce failed: {self._lib.pdt_rccl_last_error().decode()}")
 
     def broadcast_(self, tensor, src=0):
-        stream = torch.cuda.current_stream(self.comm.device).cuda_stream
-        self.comm.broadcast_(tensor, src=src, stream=stream)
+        """Blocking broadcast (control-plane use only): runs on the communication stream, fenced on both sides."""
+        torch.cuda.current_stream(self.comm.device).synchronize()
+        self.comm.broadcast_(tensor, src=src)
+        self.comm.synchronize()
 
     def close(self):
         if self._state:
