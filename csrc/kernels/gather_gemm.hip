@@ -39,18 +39,25 @@ struct GatherGemmArgs {
     int Hout, Wout, ostr, oph, opw;
     FastDiv div_ab;  // divide by OA*OB
     FastDiv div_b;   // divide by OB
+    FastDiv div_c;   // divide by C (few-channel mode)
     int OA, OB;
     int tap_dh[GG_MAX_TAPS];
     int tap_dw[GG_MAX_TAPS];
     int tap_woff[GG_MAX_TAPS];
 };
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p) {
+// SMALLC: few input channels (the 3-channel stem).  The reduction index k = tap*C + c is decoded per element
+// and the operand is gathered with 2-byte loads (the whole image batch is cache resident); B rows hold the
+// weights in (tap, c) order zero-padded to a multiple of 64.  No patch matrix is materialised.
+template <int BM, int BN, int WM, int WN, bool SMALLC>
+__global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherGemmArgs p) {
+    constexpr int NT = WM * WN * 64;           // threads per workgroup (4 or 8 waves)
     constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
     constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
-    constexpr int AP = BM / 32, BP = BN / 32;  // loader passes (32 rows x 8 chunks per pass)
-    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int LR = NT / 8;                 // rows covered by one loader pass (8 chunks per row)
+    constexpr int AP = BM / LR, BP = BN / LR;  // loader passes
+    static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
+    static_assert(BM % LR == 0 && BN % LR == 0, "tile rows must be a multiple of the loader pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // staging buffers: [stage][A tile BM x 64 | B tile BN x 64]; a single-step launch touches stage 0 only
     constexpr int STAGE = (BM + BN) * GG_BK;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
     int a_pix[AP], a_h[AP], a_w[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + LR * i;
         if (m < p.M) {
             const uint32_t img = fastdiv(m, p.div_ab);
             const uint32_t rem = m - img * (p.OA * p.OB);
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
     bool b_ok[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-        const int n = n0 + lrow + 32 * i;
+        const int n = n0 + lrow + LR * i;
         b_ok[i] = n < p.N;
         b_off[i] = (b_ok[i] ? n : 0) * p.ldb + chunk * 8;
     }
@@ -100,11 +107,40 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int csteps = p.C / GG_BK;
-    const int nsteps = p.T * csteps;
+    const int nsteps = SMALLC ? (p.T * p.C + GG_BK - 1) / GG_BK : p.T * csteps;
     bf16x8 ra[AP], rb[BP];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     auto load_step = [&](int t, int c0) {
+        if (SMALLC) {
+            // here t is the K-step index: this thread's 8 reduction indices are k0 .. k0+7
+            const int k0 = t * GG_BK + chunk * 8;
+            int e_dh[8], e_dw[8], e_c[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                const int tap = min(static_cast<int>(fastdiv(k, p.div_c)), p.T - 1);
+                e_c[e] = k - tap * p.C;
+                const bool kv = k < p.T * p.C;
+                e_dh[e] = kv ? p.tap_dh[tap] : -(1 << 24);
+                e_dw[e] = p.tap_dw[tap];
+            }
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ih = a_h[i] + e_dh[e], iw = a_w[i] + e_dw[e];
+                    const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                                    static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+                    const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.C + e_c[e];
+                    ra[i][e] = ok ? p.A[off] : static_cast<bf16>(0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BP; ++i)
+                rb[i] = b_ok[i] ? *reinterpret_cast<const bf16x8*>(p.B + b_off[i] + t * GG_BK) : zero8;
+            return;
+        }
         const int dh = p.tap_dh[t], dw = p.tap_dw[t], woff = p.tap_woff[t] + c0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -121,12 +157,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int row = lrow + 32 * i;
+            const int row = lrow + LR * i;
             *reinterpret_cast<bf16x8*>(sA + buf * STAGE + row * GG_BK + ((chunk ^ (row & 7)) << 3)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const int row = lrow + 32 * i;
+            const int row = lrow + LR * i;
             *reinterpret_cast<bf16x8*>(sB + buf * STAGE + row * GG_BK + ((chunk ^ (row & 7)) << 3)) = rb[i];
         }
     };
@@ -161,10 +197,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
         for (int s = 0; s < nsteps; ++s) {
             const bool more = s + 1 < nsteps;
             if (more) {
-                c0 += GG_BK;
-                if (c0 >= p.C) {
-                    c0 = 0;
+                if (SMALLC) {
                     ++t;
+                } else {
+                    c0 += GG_BK;
+                    if (c0 >= p.C) {
+                        c0 = 0;
+                        ++t;
+                    }
                 }
                 load_step(t, c0);
             }
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
     __syncthreads();
 
     constexpr int CH = BN / 8;      // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CH;   // rows per pass
+    constexpr int RPP = NT / CH;    // rows per pass
     constexpr int NPASS = BM / RPP;
     const int ch = tid % CH, prow = tid / CH;
     const int ncol = n0 + ch * 8;
@@ -242,7 +282,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
         }
         __syncthreads();
         float* slot = p.stats + static_cast<size_t>(tile_m % PDT_STAT_SLOTS) * 2 * p.N;
-        for (int idx = tid; idx < 2 * BN; idx += 256) {
+        for (int idx = tid; idx < 2 * BN; idx += NT) {
             const int which = idx / BN, col = idx - which * BN;
             float tot = 0.f;
             for (int r = 0; r < RPP; ++r) tot += sS[(r * 2 + which) * BN + col];
@@ -252,20 +292,20 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmArgs p
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool SMALLC = false>
 static int launch_gather_gemm(const GatherGemmArgs& a, hipStream_t stream) {
     const int grid = pdt_cdiv(a.M, BM) * pdt_cdiv(a.N, BN);
     constexpr size_t lds_loop = 2ull * (BM + BN) * GG_BK * sizeof(bf16);
     constexpr size_t lds_epi = static_cast<size_t>(BM) * (BN + 8) * sizeof(bf16);
-    constexpr size_t lds_stats = (256 / (BN / 8)) * 2ull * BN * sizeof(float);
+    constexpr size_t lds_stats = ((WM * WN * 64) / (BN / 8)) * 2ull * BN * sizeof(float);
     constexpr size_t lds_full = lds_loop > lds_epi ? (lds_loop > lds_stats ? lds_loop : lds_stats)
                                                    : (lds_epi > lds_stats ? lds_epi : lds_stats);
     // A single K-step touches only the first staging buffer: request half the loop LDS so twice as many
     // workgroups are resident (these launches are bound by their loads and stores, not by MFMA).
     constexpr size_t lds_half = (lds_loop / 2) > lds_epi ? ((lds_loop / 2) > lds_stats ? lds_loop / 2 : lds_stats)
                                                          : (lds_epi > lds_stats ? lds_epi : lds_stats);
-    const size_t lds = (a.T * (a.C / GG_BK) <= 1) ? lds_half : lds_full;
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, stream, a);
+    const size_t lds = (!SMALLC && a.T * (a.C / GG_BK) <= 1) ? lds_half : lds_full;
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, SMALLC>), dim3(grid), dim3(WM * WN * 64), lds, stream, a);
     return pdt_launch_status();
 }
 
@@ -276,8 +316,10 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             const void* addend, int M, int N,
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
-                            const int* tap_woff, int tile, void* stream) {
-    if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0 || (C % GG_BK) != 0) return -1;
+                            const int* tap_woff, int tile, int smallc, void* stream) {
+    if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
+    if (!smallc && (C % GG_BK) != 0) return -1;
+    if (smallc && (T == 0 || ldb < (T * C + GG_BK - 1) / GG_BK * GG_BK)) return -1;  // B rows padded to whole K-steps
     if ((ldo % 8) != 0 || (ldb % 8) != 0 || OA <= 0 || OB <= 0) return -1;
     GatherGemmArgs a;
     a.A = static_cast<const bf16*>(A);
@@ -292,17 +334,23 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.OA = OA; a.OB = OB;
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
     a.div_b = make_fastdiv(OB);
+    a.div_c = make_fastdiv(C);
     for (int t = 0; t < T; ++t) {
-        if ((tap_woff[t] % 8) != 0) return -1;
+        if (!smallc && (tap_woff[t] % 8) != 0) return -1;
         a.tap_dh[t] = tap_dh[t];
         a.tap_dw[t] = tap_dw[t];
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (smallc) return N <= 64 ? launch_gather_gemm<128, 64, 4, 1, true>(a, s) : launch_gather_gemm<128, 128, 2, 2, true>(a, s);
     switch (tile) {
         case 0: return launch_gather_gemm<128, 128, 2, 2>(a, s);
         case 1: return launch_gather_gemm<128, 64, 4, 1>(a, s);
         case 2: return launch_gather_gemm<64, 64, 2, 2>(a, s);
+        case 3: return launch_gather_gemm<128, 128, 4, 2>(a, s);  // 8 waves, 32x64 per wave
+        case 4: return launch_gather_gemm<128, 128, 2, 4>(a, s);  // 8 waves, 64x32 per wave
+        case 5: return launch_gather_gemm<128, 64, 4, 2>(a, s);   // 8 waves, 32x32 per wave
+        case 6: return launch_gather_gemm<256, 128, 4, 2>(a, s);  // 8 waves, 64x64 per wave
         default: return -1;
     }
 }
@@ -321,8 +369,9 @@ struct WgradArgs {
     float* dW;
     int M, N, ldy, C, T, ldw;
     int Hin, Win, istr, OA, OB;
-    FastDiv div_ab, div_b;
+    FastDiv div_ab, div_b, div_c;
     int m_per_split;
+    int Kc;  // few-channel mode: number of valid reduction columns (taps * C); C then means the padded column count
     int tap_dh[GG_MAX_TAPS];
     int tap_dw[GG_MAX_TAPS];
     int tap_woff[GG_MAX_TAPS];
@@ -338,7 +387,9 @@ __device__ __forceinline__ bf16x8 lds_read_tr8(const bf16* base_lo, const bf16* 
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int BT>  // BT x BT output tile (n x c), BT in {64, 128}
+// SMALLC: the "channel" axis of the X operand is the flattened (tap, c) index of a few-channel convolution
+// (the stem); each element is gathered individually, see gather_gemm_kernel.
+template <int BT, bool SMALLC>  // BT x BT output tile (n x c), BT in {64, 128}
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int KM = 64;             // pixels per K-step
     constexpr int PITCH = BT + 16;     // bf16 elements per LDS row (pad 32 B: conflict-free transposed reads)
@@ -355,13 +406,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (p.N + BT - 1) / BT, tiles_c = (p.C + BT - 1) / BT;
     int bid = blockIdx.x;
-    const int tap = bid % p.T;  // taps fastest: neighbouring blocks re-read the same pixels from L2
-    bid /= p.T;
+    const int ntap = SMALLC ? 1 : p.T;
+    const int tap = bid % ntap;  // taps fastest: neighbouring blocks re-read the same pixels from L2
+    bid /= ntap;
     const int tc = bid % tiles_c, tn = bid / tiles_c;
     const int n0 = tn * BT, c0 = tc * BT;
     const int ms = blockIdx.y * p.m_per_split;
     const int me = min(p.M, ms + p.m_per_split);
-    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const int dh = SMALLC ? 0 : p.tap_dh[tap], dw = SMALLC ? 0 : p.tap_dw[tap];
 
     const int chunk = tid % CPR, lrow = tid / CPR;
     const bool y_ok = n0 + chunk * 8 < p.N;
@@ -375,6 +427,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     bf16x8 ry[NP], rx[NP];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int e_dh[8], e_dw[8], e_c[8];  // few-channel mode: decoded (tap offset, channel) of this thread's 8 columns
+    if (SMALLC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = c0 + chunk * 8 + e;
+            const int t = min(static_cast<int>(fastdiv(k, p.div_c)), p.T - 1);
+            e_c[e] = k - t * (p.Kc / p.T);
+            e_dh[e] = k < p.Kc ? p.tap_dh[t] : -(1 << 24);
+            e_dw[e] = p.tap_dw[t];
+        }
+    }
     auto load_step = [&](int mbase) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -382,6 +445,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const bool mok = m < me;
             ry[i] = (mok && y_ok) ? *reinterpret_cast<const bf16x8*>(p.dY + static_cast<size_t>(m) * p.ldy + n0 + chunk * 8)
                                   : zero8;
+            if (SMALLC) {
+                const int cr = p.Kc / p.T;  // real channel count
+                if (mok) {
+                    const uint32_t img = fastdiv(m, p.div_ab);
+                    const uint32_t rem = m - img * (p.OA * p.OB);
+                    const uint32_t a = fastdiv(rem, p.div_b);
+                    const uint32_t b = rem - a * p.OB;
+                    const int h0 = static_cast<int>(a) * p.istr, w0 = static_cast<int>(b) * p.istr;
+                    const uint32_t pix = img * (p.Hin * p.Win);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ih = h0 + e_dh[e], iw = w0 + e_dw[e];
+                        const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                                        static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+                        rx[i][e] = ok ? p.X[(pix + ih * p.Win + iw) * cr + e_c[e]] : static_cast<bf16>(0.f);
+                    }
+                } else {
+                    rx[i] = zero8;
+                }
+                continue;
+            }
             bool ok = mok && x_ok;
             uint32_t off = 0;
             if (ok) {
@@ -449,7 +533,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 
     // D[i = n][j = c]: lane holds rows (lane>>4)*4 + e, column lane&15
-    const int woff = p.tap_woff[tap];
+    const int woff = SMALLC ? 0 : p.tap_woff[tap];
 #pragma unroll
     for (int i = 0; i < F; ++i)
 #pragma unroll
@@ -468,10 +552,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // dW must be zero (or hold a value to accumulate onto) before the call.
 PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
                       int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
-                      int splits, int tile, void* stream) {
+                      int splits, int tile, int smallc, void* stream) {
     // rows of dY are read in 8-column chunks: ldy must cover N rounded up to 8 (columns >= N are ignored)
-    if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (C % 8) != 0 || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8)
-        return -1;
+    if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8) return -1;
+    if (!smallc && (C % 8) != 0) return -1;
     if (splits <= 0 || OA <= 0 || OB <= 0) return -1;
     WgradArgs a;
     a.dY = static_cast<const bf16*>(dY);
@@ -481,6 +565,15 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.Hin = Hin; a.Win = Win; a.istr = istr; a.OA = OA; a.OB = OB;
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
     a.div_b = make_fastdiv(OB);
+    a.Kc = 0;
+    a.div_c = make_fastdiv(1);
+    if (smallc) {
+        // C = real channel count on entry; the kernel sees the flattened, padded (tap, c) axis as its channel axis
+        a.Kc = T * C;
+        a.div_c = make_fastdiv(C);
+        a.C = (T * C + 7) / 8 * 8;
+        if (ldw < a.C) return -1;
+    }
     int mps = pdt_cdiv(M, splits);
     mps = pdt_cdiv(mps, 64) * 64;
     a.m_per_split = mps;
@@ -491,16 +584,21 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (tile == 0) {
+    if (smallc) {
+        constexpr int BT = 64;
+        const int gx = pdt_cdiv(N, BT) * pdt_cdiv(a.C, BT);
+        const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
+        hipLaunchKernelGGL((wgrad_kernel<BT, true>), dim3(gx, gy), dim3(256), lds, s, a);
+    } else if (tile == 0) {
         constexpr int BT = 128;
         const int gx = pdt_cdiv(N, BT) * pdt_cdiv(C, BT) * T;
         const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
-        hipLaunchKernelGGL((wgrad_kernel<BT>), dim3(gx, gy), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((wgrad_kernel<BT, false>), dim3(gx, gy), dim3(256), lds, s, a);
     } else if (tile == 1) {
         constexpr int BT = 64;
         const int gx = pdt_cdiv(N, BT) * pdt_cdiv(C, BT) * T;
         const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
-        hipLaunchKernelGGL((wgrad_kernel<BT>), dim3(gx, gy), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((wgrad_kernel<BT, false>), dim3(gx, gy), dim3(256), lds, s, a);
     } else {
         return -1;
     }

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os as _os
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -40,8 +41,8 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _vp])
-_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp])
+_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
@@ -330,25 +331,27 @@ SHADOWS = ShadowCache()
 # ------------------------------------------------------------------------------------------------
 # GEMM / convolution launch helpers
 # ------------------------------------------------------------------------------------------------
+_TILE_WIDE = int(_os.environ.get("PDT_GEMM_TILE_WIDE", "0"))
+_TILE_NARROW = int(_os.environ.get("PDT_GEMM_TILE_NARROW", "1"))
+
+
 def _pick_tile(m: int, n: int) -> int:
     if n <= 64:
-        return 1 if m >= 128 else 2
-    return 0
+        return _TILE_NARROW if m >= 128 else 2
+    return _TILE_WIDE
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None) -> None:
+                        oph, opw, addend=None, smallc=False) -> None:
     dh = _int_array([t[0] for t in taps])
     dw = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), M, N, ldb, ldo, C, len(taps),
-                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), _stream()),
+                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc), _stream()),
         "gather_gemm",
     )
 
-
-import os as _os
 
 WGRAD_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_TARGET_BLOCKS", "640"))
 WGRAD_ATOMIC_CAP_MB = int(_os.environ.get("PDT_WGRAD_ATOMIC_CAP_MB", "8"))
@@ -369,16 +372,16 @@ def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bt: int) -> int:
     return max(1, min(max(min(want, cap), floor), M // 256))
 
 
-def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB) -> None:
-    tile = 0 if (N > 64 and C > 64) else 1
+def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=False) -> None:
+    tile = 0 if (N > 64 and C > 64 and not smallc) else 1
     bt = 128 if tile == 0 else 64
-    splits = _wgrad_splits(M, N, C, len(taps), bt)
+    splits = _wgrad_splits(M, N, C * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
     dh = _int_array([t[0] for t in taps])
     dwi = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
     _check(
         _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
-               wo, splits, tile, _stream()),
+               wo, splits, tile, int(smallc), _stream()),
         "wgrad",
     )
 
@@ -430,15 +433,15 @@ class _ConvStats(torch.autograd.Function):
             _launch_gather_gemm(x, wb, y, stats, None, M, n, r * s * c, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0)
             ctx.save_for_backward(x, weight)
         else:
-            # few input channels (the stem): explicit patch matrix, then a plain GEMM
-            k = r * s * c
-            kpad = _round_up(k, 64)
-            col = torch.empty((M, kpad), dtype=torch.bfloat16, device=x.device)
-            _check_size(col)
-            _check(_im2col(x.data_ptr(), col.data_ptr(), nb, h, w_, c, r, s, stride, padding, kpad, _stream()), "im2col")
+            # few input channels (the stem): the kernel decodes (tap, channel) per element, no patch matrix
+            if r * s > 49:
+                raise ValueError("few-channel convolutions support at most 49 taps")
+            kpad = _round_up(r * s * c, 64)
             wb = SHADOWS.fwd(weight, pad_cols_to=64)
-            _launch_gather_gemm(col, wb, y, stats, None, M, n, kpad, n, kpad, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
-            ctx.save_for_backward(col, weight)
+            taps = [(i - padding, j - padding, 0) for i in range(r) for j in range(s)]
+            _launch_gather_gemm(x, wb, y, stats, None, M, n, kpad, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0,
+                                smallc=True)
+            ctx.save_for_backward(x, weight)
             ctx.col = kpad
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -464,7 +467,8 @@ class _ConvStats(torch.autograd.Function):
             else:
                 kpad = ctx.col
                 dwp = torch.zeros((n, kpad), dtype=torch.float32, device=dy.device)
-                _launch_wgrad(dy, saved, dwp, M, n, n, kpad, [(0, 0, 0)], kpad, 1, 1, 1, 1, 1)
+                taps = [(i - padding, j - padding, 0) for i in range(r) for j in range(s)]
+                _launch_wgrad(dy, saved, dwp, M, n, n, c, taps, kpad, h, w_, stride, ho, wo, smallc=True)
                 dw = dwp[:, : r * s * c].reshape(n, r, s, c).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[0]:
             if ctx.col is not None:

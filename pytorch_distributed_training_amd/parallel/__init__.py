@@ -2,6 +2,10 @@
 
 from __future__ import annotations
 
+import torch
+import torch.distributed as dist
+
+from ..utils.logging import get_logger
 from .env import DistEnv, barrier, init_distributed, select_backend, shutdown  # noqa: F401
 from .reducer import BucketedDataParallel, BucketPlan, GradReducer, plan_buckets  # noqa: F401
 from .transport import (  # noqa: F401
@@ -19,8 +23,17 @@ def make_transport(env: DistEnv, native_rccl: bool = True) -> Transport:
     if not env.distributed:
         raise ValueError("no process group: data parallelism needs --distributed")
     if env.backend == "nccl" and native_rccl:
-        comm = RcclComm(env.rank, env.world_size, env.device)
-        return RcclTransport(comm)
+        try:
+            comm = RcclComm(env.rank, env.world_size, env.device)
+        except Exception as e:  # e.g. the native library is missing on this box: say so, keep the job alive
+            ok = torch.tensor([0.0], device=env.device)
+            get_logger("pdt.parallel").warning("own RCCL communicator unavailable (%s); using torch.distributed all-reduce", e)
+        else:
+            ok = torch.tensor([1.0], device=env.device)
+        # every rank must pick the same transport
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok) > 0:
+            return RcclTransport(comm)
     return TorchDistTransport()
 
 
