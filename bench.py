@@ -29,7 +29,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-size", type=int, default=512, help="per-GPU batch (sized for 288 GB of HBM)")
+    ap.add_argument("--batch-size", type=int, default=1024, help="per-GPU batch (sized for 288 GB of HBM)")
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=1024)

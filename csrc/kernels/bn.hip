@@ -74,7 +74,7 @@ template <bool RELU, int IDENT>  // IDENT: 0 none, 1 plain tensor, 2 tensor with
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ consts,
                                                           const bf16* __restrict__ ident,
                                                           const float* __restrict__ iconsts, bf16* __restrict__ out,
-                                                          long long nvec, int C) {
+                                                          uint8_t* __restrict__ bits, long long nvec, int C) {
     const int cvec = C >> 3;
     for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
         const int c = static_cast<int>(v % cvec) << 3;
@@ -98,9 +98,14 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const bf16* __restric
             for (int e = 0; e < 8; ++e) z[e] += bf16_to_f32(iv[e]) * isc[e] + ish[e];
         }
         bf16x8 o;
+        unsigned m = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(RELU ? fmaxf(z[e], 0.f) : z[e]);
+        for (int e = 0; e < 8; ++e) {
+            o[e] = f32_to_bf16(RELU ? fmaxf(z[e], 0.f) : z[e]);
+            m |= (bf16_to_f32(o[e]) > 0.f ? 1u : 0u) << e;
+        }
         *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+        if (bits != nullptr) bits[v] = static_cast<uint8_t>(m);  // ReLU mask, one bit per element, for backward
     }
 }
 
@@ -109,24 +114,26 @@ static inline int ew_grid(long long nvec) {
     return static_cast<int>(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// bits (optional): [numel / 8] bytes receiving the ReLU mask of the output (bit e of byte v = out[8v + e] > 0).
 PDT_API int pdt_bn_apply_fwd(const void* y, const float* consts, const void* ident, const float* iconsts, void* out,
-                             long long numel, int C, int relu, void* stream) {
+                             void* bits, long long numel, int C, int relu, void* stream) {
     if (C <= 0 || (C % 8) != 0 || numel <= 0 || (numel % C) != 0) return -1;
     const long long nvec = numel / 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16* yy = static_cast<const bf16*>(y);
     const bf16* id = static_cast<const bf16*>(ident);
     bf16* o = static_cast<bf16*>(out);
+    uint8_t* bt = static_cast<uint8_t*>(bits);
     const dim3 g(ew_grid(nvec)), b(256);
     if (ident == nullptr) {
-        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 0>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
-        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 0>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 0>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
+        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 0>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
     } else if (iconsts == nullptr) {
-        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 1>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
-        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 1>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 1>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
+        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 1>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
     } else {
-        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 2>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
-        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 2>), g, b, 0, s, yy, consts, id, iconsts, o, nvec, C);
+        if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 2>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
+        else hipLaunchKernelGGL((bn_apply_fwd_kernel<false, 2>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
     }
     return pdt_launch_status();
 }
@@ -135,7 +142,8 @@ PDT_API int pdt_bn_apply_fwd(const void* y, const float* consts, const void* ide
 // backward reduction:  slots[S][3][C] += (sum dz, sum dz*xhat, sum dz*xhat2),  dz = dout * [out > 0]
 //   workgroup = 32 row-lanes x 8 chunks (64 channels); grid.x = row blocks, grid.y = channel groups
 // ------------------------------------------------------------------------------------------------
-// MASK: 0 = dz is dout, 1 = mask from the stored output (out > 0), 2 = mask recomputed as y*scale + shift > 0
+// MASK: 0 = dz is dout, 1 = mask from the stored output (out > 0), 2 = mask recomputed as y*scale + shift > 0,
+//       3 = mask from the bit array written by the forward kernel (passed through the `out` pointer)
 template <int MASK, bool SECOND>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
                                                            const bf16* __restrict__ y, const float* __restrict__ consts,
@@ -170,7 +178,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
             const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + off);
             const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + off);
             bf16x8 ov, y2v;
+            unsigned mbits = 0;
             if (MASK == 1) ov = *reinterpret_cast<const bf16x8*>(out + off);
+            if (MASK == 3) mbits = reinterpret_cast<const uint8_t*>(out)[off >> 3];
             if (SECOND) y2v = *reinterpret_cast<const bf16x8*>(y2 + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
                 const float yf = bf16_to_f32(yv[e]);
                 if (MASK == 1) dz = bf16_to_f32(ov[e]) > 0.f ? dz : 0.f;
                 if (MASK == 2) dz = (yf * sc[e] + sh[e]) > 0.f ? dz : 0.f;
+                if (MASK == 3) dz = ((mbits >> e) & 1u) ? dz : 0.f;
                 s1[e] += dz;
                 s2[e] += dz * (yf - mu[e]) * rs[e];
                 if (SECOND) s3[e] += dz * (bf16_to_f32(y2v[e]) - mu2[e]) * rs2[e];
@@ -217,7 +228,8 @@ static inline int reduce_rows_per_block(int M, int C) {
 // slots: zero-initialised [PDT_STAT_SLOTS][3][C].  mask_mode: 0 none, 1 from `out`, 2 recomputed from y.
 PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, const float* consts, const void* y2,
                               const float* consts2, float* slots, int M, int C, int mask_mode, void* stream) {
-    if (M <= 0 || C <= 0 || (C % 8) != 0 || mask_mode < 0 || mask_mode > 2 || (mask_mode == 1 && out == nullptr)) return -1;
+    if (M <= 0 || C <= 0 || (C % 8) != 0 || mask_mode < 0 || mask_mode > 3) return -1;
+    if ((mask_mode == 1 || mask_mode == 3) && out == nullptr) return -1;
     const int rpb = reduce_rows_per_block(M, C);
     const dim3 g(pdt_cdiv(M, rpb), pdt_cdiv(C, 64)), b(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -227,6 +239,7 @@ PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, 
 #define PDT_RED(MK, SC) hipLaunchKernelGGL((bn_bwd_reduce_kernel<MK, SC>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb)
     if (mask_mode == 1) { if (second) PDT_RED(1, true); else PDT_RED(1, false); }
     else if (mask_mode == 2) { if (second) PDT_RED(2, true); else PDT_RED(2, false); }
+    else if (mask_mode == 3) { if (second) PDT_RED(3, true); else PDT_RED(3, false); }
     else { if (second) PDT_RED(0, true); else PDT_RED(0, false); }
 #undef PDT_RED
     return pdt_launch_status();
@@ -298,6 +311,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
             load8f(consts + 3 * C + c, sh);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dz[e] = (bf16_to_f32(yv[e]) * sc[e] + sh[e]) > 0.f ? bf16_to_f32(dv[e]) : 0.f;
+        } else if (MASK == 3) {
+            const unsigned mbits = reinterpret_cast<const uint8_t*>(out)[v];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dz[e] = ((mbits >> e) & 1u) ? bf16_to_f32(dv[e]) : 0.f;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dz[e] = bf16_to_f32(dv[e]);
@@ -331,7 +348,9 @@ PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, c
                              void* dy, void* dz_out, const void* y2, const float* coef2, void* dy2, long long numel,
                              int C, int mask_mode, void* stream) {
     if (C <= 0 || (C % 8) != 0 || numel <= 0 || (numel % C) != 0) return -1;
-    if (mask_mode < 0 || mask_mode > 2 || (mask_mode == 1 && out == nullptr) || (mask_mode == 2 && consts == nullptr)) return -1;
+    if (mask_mode < 0 || mask_mode > 3 || ((mask_mode == 1 || mask_mode == 3) && out == nullptr) ||
+        (mask_mode == 2 && consts == nullptr))
+        return -1;
     if (dz_out != nullptr && y2 != nullptr) return -1;  // identity is either plain (needs dz) or projected (needs dy2)
     const long long nvec = numel / 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -349,6 +368,7 @@ PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, c
     } while (0)
     if (mask_mode == 1) PDT_APPLY_M(1);
     else if (mask_mode == 2) PDT_APPLY_M(2);
+    else if (mask_mode == 3) PDT_APPLY_M(3);
     else PDT_APPLY_M(0);
 #undef PDT_APPLY_M
 #undef PDT_APPLY

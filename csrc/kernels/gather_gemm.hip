@@ -34,6 +34,7 @@ struct GatherGemmArgs {
     float* stats;       // [PDT_STAT_SLOTS][2][N] zero-initialised (sum, sumsq) accumulators, or nullptr
     const float* bias;  // [N] or nullptr
     const bf16* addend; // tensor with the layout of Out added to the result (residual gradient), or nullptr
+    const uint8_t* addend_bits;  // optional ReLU mask for the addend: bit e of byte v gates element 8v + e
     int M, N, ldb, ldo, C, T;
     int Hin, Win, istr;
     int Hout, Wout, ostr, oph, opw;
@@ -258,8 +259,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
             const size_t pix = (static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw;
             if (p.addend != nullptr) {
                 const bf16x8 av = *reinterpret_cast<const bf16x8*>(p.addend + pix * p.ldo + ncol);
+                const unsigned mb = p.addend_bits != nullptr ? p.addend_bits[(pix * p.ldo + ncol) >> 3] : 0xffu;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) + bf16_to_f32(av[e]));
+                for (int e = 0; e < 8; ++e)
+                    v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((mb >> e) & 1u) ? bf16_to_f32(av[e]) : 0.f));
             }
             *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
 #pragma unroll
@@ -313,7 +316,7 @@ static int launch_gather_gemm(const GatherGemmArgs& a, hipStream_t stream) {
 //   tile: 0 = 128x128, 1 = 128x64 (narrow N), 2 = 256x128... (see switch)
 // Returns 0 on success, -1 on invalid arguments, otherwise a hipError_t.
 PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stats, const float* bias,
-                            const void* addend, int M, int N,
+                            const void* addend, const void* addend_bits, int M, int N,
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
                             const int* tap_woff, int tile, int smallc, void* stream) {
@@ -328,6 +331,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.stats = stats;
     a.bias = bias;
     a.addend = static_cast<const bf16*>(addend);
+    a.addend_bits = static_cast<const uint8_t*>(addend_bits);
     a.M = M; a.N = N; a.ldb = ldb; a.ldo = ldo; a.C = C; a.T = T;
     a.Hin = Hin; a.Win = Win; a.istr = istr;
     a.Hout = Hout; a.Wout = Wout; a.ostr = ostr; a.oph = oph; a.opw = opw;

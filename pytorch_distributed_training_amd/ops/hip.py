@@ -41,10 +41,10 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
-_bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
+_bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
 _bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 _bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
@@ -342,12 +342,13 @@ def _pick_tile(m: int, n: int) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None, smallc=False) -> None:
+                        oph, opw, addend=None, smallc=False, addend_bits=None) -> None:
     dh = _int_array([t[0] for t in taps])
     dw = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
     _check(
-        _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), M, N, ldb, ldo, C, len(taps),
+        _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
+                     ldb, ldo, C, len(taps),
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc), _stream()),
         "gather_gemm",
     )
@@ -395,10 +396,11 @@ class ResidualLink:
     kernel of the block's first convolution, which adds it in its epilogue.  Both consume the same block
     input ``x``; without the link autograd would materialise both gradients and add them in a separate pass."""
 
-    __slots__ = ("grad", "armed")
+    __slots__ = ("grad", "bits", "armed")
 
     def __init__(self):
-        self.grad = None
+        self.grad = None   # gradient tensor to add (the block output's gradient)
+        self.bits = None   # optional ReLU mask bits gating it (then grad * mask is what gets added)
         self.armed = False  # set in forward by the convolution that will consume the gradient
 
 
@@ -477,9 +479,10 @@ class _ConvStats(torch.autograd.Function):
             if npad != n:
                 raise NotImplementedError("data gradient needs Cout % 64 == 0")
             dx = _empty_nhwc(nb, c, h, w_, dy.device)
-            addend = None
+            addend = addend_bits = None
             if ctx.link is not None and ctx.link.grad is not None:
-                addend, ctx.link.grad = _as_nhwc(ctx.link.grad), None
+                addend, addend_bits = _as_nhwc(ctx.link.grad), ctx.link.bits
+                ctx.link.grad = ctx.link.bits = None
                 if addend.shape != dx.shape:
                     raise RuntimeError("residual link carries a gradient of the wrong shape")
             for ph in range(stride):
@@ -499,7 +502,7 @@ class _ConvStats(torch.autograd.Function):
                                 continue
                             taps.append(((ph + padding - i) // stride, (pw + padding - j) // stride, (i * s + j) * npad))
                     _launch_gather_gemm(dy, wt, dx, None, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
-                                        oa, ob, h, w_, stride, ph, pw, addend)
+                                        oa, ob, h, w_, stride, ph, pw, addend, addend_bits=addend_bits)
         elif ctx.link is not None and ctx.link.grad is not None:
             raise RuntimeError("residual link armed but the convolution input needs no gradient")
         return dx, dw, None, None, None, None
@@ -589,7 +592,7 @@ class _BnAct(torch.autograd.Function):
         count = nb * h * w
         consts = _bn_consts(stats, bn, count, y.device)
         out = torch.empty_like(y)
-        _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), None, None, out.data_ptr(), y.numel(), c, int(relu),
+        _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), None, None, out.data_ptr(), None, y.numel(), c, int(relu),
                              _stream()), "bn_apply_fwd")
         ctx.save_for_backward(y, consts, gamma, beta)
         ctx.meta = (count, c, relu)
@@ -616,27 +619,32 @@ class _BnAddRelu(torch.autograd.Function):
         consts = _bn_consts(stats, bn, count, y.device)
         iconsts = _bn_consts(id_stats, id_bn, count, y.device) if id_bn is not None else None
         out = torch.empty_like(y)
-        _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), ident.data_ptr(), _ptr(iconsts), out.data_ptr(), y.numel(),
-                             c, 1, _stream()), "bn_apply_fwd")
+        # one mask bit per element replaces re-reading the whole output tensor in both backward passes
+        bits = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device) if ctx.needs_input_grad[0] else None
+        _check(_bn_apply_fwd(y.data_ptr(), consts.data_ptr(), ident.data_ptr(), _ptr(iconsts), out.data_ptr(), _ptr(bits),
+                             y.numel(), c, 1, _stream()), "bn_apply_fwd")
         ctx.projected = id_bn is not None
         ctx.link = link if (link is not None and link.armed and not ctx.projected) else None
-        ctx.save_for_backward(y, out, consts, gamma, beta, ident if ctx.projected else None, iconsts, id_gamma, id_beta)
+        ctx.save_for_backward(y, bits, consts, gamma, beta, ident if ctx.projected else None, iconsts, id_gamma, id_beta)
         ctx.meta = (count, c)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, out, consts, gamma, beta, ident, iconsts, id_gamma, id_beta = ctx.saved_tensors
+        y, bits, consts, gamma, beta, ident, iconsts, id_gamma, id_beta = ctx.saved_tensors
         count, c = ctx.meta
         dout = _as_nhwc(dout)
         if ctx.projected:
-            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, out, y, consts, gamma, beta, count, c, ident,
-                                                                      iconsts, id_gamma, id_beta)
+            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, ident,
+                                                                      iconsts, id_gamma, id_beta, mask_mode=3)
             return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None, None
-        dy, dgamma, dbeta, dz = _bn_backward(dout, out, y, consts, gamma, beta, count, c, want_dz=True)
         if ctx.link is not None:
-            ctx.link.grad = dz  # added to the first convolution's data gradient in that kernel's epilogue
-            dz = None
+            # the shortcut gradient dz = dout * mask is not materialised: the first convolution's data-gradient
+            # kernel forms it from (dout, mask bits) while adding it in its epilogue
+            dy, dgamma, dbeta, _ = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, mask_mode=3)
+            ctx.link.grad, ctx.link.bits = dout, bits
+            return dy, None, dgamma, dbeta, None, None, None, None, None, None, None
+        dy, dgamma, dbeta, dz = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, want_dz=True, mask_mode=3)
         return dy, None, dgamma, dbeta, None, dz, None, None, None, None, None
 
 
