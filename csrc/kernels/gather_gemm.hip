@@ -35,6 +35,7 @@ struct GatherGemmArgs {
     const float* bias;  // [N] or nullptr
     const bf16* addend; // tensor with the layout of Out added to the result (residual gradient), or nullptr
     const uint8_t* addend_bits;  // optional ReLU mask for the addend: bit e of byte v gates element 8v + e
+    const bf16* zeros;  // >= 16 bytes of zeros (ring variant: source of rows that are padding); may be nullptr otherwise
     int M, N, ldb, ldo, C, T;
     int Hin, Win, istr;
     int Hout, Wout, ostr, oph, opw;
@@ -312,6 +313,304 @@ static int launch_gather_gemm(const GatherGemmArgs& a, hipStream_t stream) {
     return pdt_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant: persistent workgroups, operands staged by LDS-DMA into a ring of NS stages.
+//
+// The kernel above keeps one K-step of loads in flight per workgroup and nothing during its epilogue, so
+// launches with few K-steps per tile (the 1x1 convolutions) run at the latency of their loads.  Here
+//   * a workgroup walks a strided sequence of output tiles; the K-steps of all its tiles form one
+//     stream, so the loads of the next tile are in flight while the current tile is being written;
+//   * every stage is filled by `global_load_lds_dwordx4` (no staging registers, no ds_write); the LDS
+//     image is lane-linear per instruction (8 rows x 128 B), so the XOR swizzle is applied to the
+//     per-lane SOURCE address and again by the fragment reads;
+//   * NS - 2 stages stay in flight across the single barrier of a K-step: counted `s_waitcnt vmcnt`
+//     for this wave's own loads of the stage about to be read, then a raw `s_barrier`;
+//   * rows outside the image or beyond M / N read a page of zeros instead of being predicated off
+//     (an LDS-DMA lane that does not execute would leave stale data in the stage);
+//   * the epilogue is private to a wave (16 rows at a time through 2 KB of LDS, no workgroup barrier)
+//     and BatchNorm partial sums stay in registers across tiles: one round of atomics per workgroup.
+//
+// vmcnt also counts the epilogue's stores and loads; they are younger than the loads a wait targets, so
+// the constant used in the K-loop is at worst stricter than needed, never too weak.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_cvoid_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// EPI selects what the epilogue reads besides the accumulators: 0 nothing, 1 bias, 2 addend (+ mask bits).
+// It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
+// DMA queue (vmcnt(0)) at its use.
+template <int BM, int BN, int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const GatherGemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int AI = (BM / 8) / NW, BI = (BN / 8) / NW;  // LDS-DMA instructions per wave and stage
+    constexpr int LPW = AI + BI;
+    constexpr int STAGE = (BM + BN) * GG_BK;               // elements per ring stage: [A tile | B tile]
+    constexpr int EP = TN;                                 // pitch of the wave-private epilogue rows (chunks XOR-swizzled by row)
+    constexpr int CH = TN / 8;                             // 16-byte chunks per epilogue row
+    constexpr int RPP = 64 / CH;                           // rows per epilogue pass
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole DMA instructions per wave");
+    static_assert(NS >= 3 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
+    static_assert(16 % RPP == 0, "epilogue passes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* ring = reinterpret_cast<bf16*>(smem);  // [NS][STAGE], then [NW][16][EP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    bf16* epi = ring + NS * STAGE + wave * 16 * EP;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total_tiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int my_tiles = (total_tiles - first + G - 1) / G;
+    const int csteps = p.C / GG_BK;
+    const int nsteps = p.T * csteps;
+    const int total_steps = my_tiles * nsteps;
+
+    // ---- loader: a cursor over (tile, tap, channel block) that runs NS - 1 stages ahead of the MFMAs
+    const int lrow = lane >> 3;                               // row of this lane inside an 8-row DMA piece
+    const int kchunk = ((lane & 7) ^ lrow) << 3;              // swizzled source chunk (rows start at multiples of 8)
+    int ld_tile = first, ld_t = 0, ld_c0 = 0, ld_issued = 0, ld_slot = 0;
+    int a_pix[AI], a_h[AI], a_w[AI];
+    int b_off[BI];
+    auto loader_tile = [&](int tile) {
+        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = tile_m * BM + (wave * AI + i) * 8 + lrow;
+            if (m < p.M) {
+                const uint32_t img = fastdiv(m, p.div_ab);
+                const uint32_t rem = m - img * (p.OA * p.OB);
+                const uint32_t a = fastdiv(rem, p.div_b);
+                const uint32_t b = rem - a * p.OB;
+                a_pix[i] = img * (p.Hin * p.Win);
+                a_h[i] = a * p.istr;
+                a_w[i] = b * p.istr;
+            } else {
+                a_pix[i] = 0;
+                a_h[i] = -(1 << 24);
+                a_w[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int n = tile_n * BN + (wave * BI + i) * 8 + lrow;
+            b_off[i] = n < p.N ? n * p.ldb : -1;
+        }
+    };
+    auto issue_stage = [&]() {
+        const int dh = p.tap_dh[ld_t], dw = p.tap_dw[ld_t], woff = p.tap_woff[ld_t] + ld_c0 + kchunk;
+        bf16* sA = ring + ld_slot * STAGE;
+        bf16* sB = sA + BM * GG_BK;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int ih = a_h[i] + dh, iw = a_w[i] + dw;
+            const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                            static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+            const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.C + ld_c0 + kchunk;
+            const bf16* src = ok ? p.A + off : p.zeros;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + (wave * AI + i) * 8 * GG_BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const bf16* src = b_off[i] >= 0 ? p.B + static_cast<uint32_t>(b_off[i] + woff) : p.zeros;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sB + (wave * BI + i) * 8 * GG_BK), 16, 0, 0);
+        }
+        ++ld_issued;
+        ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
+        ld_c0 += GG_BK;
+        if (ld_c0 >= p.C) {
+            ld_c0 = 0;
+            if (++ld_t == p.T) {
+                ld_t = 0;
+                ld_tile += G;
+                if (ld_tile < total_tiles) loader_tile(ld_tile);
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+    auto compute = [&](int slot) {
+        const bf16* sA = ring + slot * STAGE;
+        const bf16* sB = sA + BM * GG_BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[FM], fb[FN];
+            const int kc = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * TM + i * 16 + (lane & 15);
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + row * GG_BK + ((kc ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * TN + j * 16 + (lane & 15);
+                fb[j] = *reinterpret_cast<const bf16x8*>(sB + row * GG_BK + ((kc ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // BatchNorm partial sums of this lane's 8 channels, carried across tiles
+    const int ech = lane % CH, erow = lane / CH;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    int stats_n0 = -1;
+    auto flush_stats = [&]() {
+        if (p.stats == nullptr || stats_n0 < 0) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = CH; o < 64; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        const int ncol = stats_n0 + wn * TN + ech * 8;
+        if (lane < CH && ncol < p.N) {
+            float* slot = p.stats + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 2 * p.N;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __hip_atomic_fetch_add(slot + ncol + e, s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(slot + p.N + ncol + e, s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    };
+
+    if (total_steps > 0) {
+        loader_tile(first);
+#pragma unroll
+        for (int k = 0; k < NS - 1; ++k)
+            if (ld_issued < total_steps) issue_stage();
+    }
+
+    int g = 0, slot = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int tile = first + ti * G;
+        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int s = 0; s < nsteps; ++s, ++g) {
+            // stage g was issued NS - 1 steps ago; in steady state NS - 2 younger stages stay in flight
+            if (ld_issued - (g + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
+            else wait_vm_and_barrier<0>();
+            // every wave has finished reading the stage of step g - 1: refill it
+            if (ld_issued < total_steps) issue_stage();
+            compute(slot);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+
+        // ---- epilogue (wave-private): 16 rows at a time -> bf16 -> LDS -> 16-byte row segments
+        if (n0 != stats_n0) {
+            flush_stats();
+            stats_n0 = n0;
+        }
+        const int ncol = n0 + wn * TN + ech * 8;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nl = j * 16 + (lane >> 4) * 4;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == 1) {
+                    const int n = n0 + wn * TN + nl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = p.bias[min(n + e, p.N - 1)];
+                }
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(acc[i][j][e] + bv[e]);
+                const int er = lane & 15;
+                *reinterpret_cast<bf16x4*>(epi + er * EP + ((((nl >> 3) ^ er) & (CH - 1)) << 3) + (nl & 4)) = v;
+            }
+#pragma unroll
+            for (int ps = 0; ps < 16 / RPP; ++ps) {
+                const int row = ps * RPP + erow;
+                const int m = m0 + wm * TM + i * 16 + row;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(epi + row * EP + (((ech ^ row) & (CH - 1)) << 3));
+                if (m < p.M && ncol < p.N) {
+                    const uint32_t img = fastdiv(m, p.div_ab);
+                    const uint32_t rem = m - img * (p.OA * p.OB);
+                    const uint32_t a = fastdiv(rem, p.div_b);
+                    const uint32_t b = rem - a * p.OB;
+                    const size_t pix = (static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw;
+                    if (EPI == 2) {
+                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(p.addend + pix * p.ldo + ncol);
+                        const unsigned mb = p.addend_bits != nullptr ? p.addend_bits[(pix * p.ldo + ncol) >> 3] : 0xffu;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((mb >> e) & 1u) ? bf16_to_f32(av[e]) : 0.f));
+                    }
+                    *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = bf16_to_f32(v[e]);
+                        s1[e] += f;
+                        s2[e] += f * f;
+                    }
+                }
+            }
+        }
+    }
+    flush_stats();
+}
+
+static int pdt_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int EPI>
+static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stream) {
+    constexpr size_t lds = (static_cast<size_t>(NS) * (BM + BN) * GG_BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
+    static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
+    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI>;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured = true;
+    }
+    const int per_cu = static_cast<int>((160 * 1024) / lds);
+    const long long tiles = static_cast<long long>(pdt_cdiv(a.M, BM)) * pdt_cdiv(a.N, BN);
+    const long long cap = static_cast<long long>(pdt_num_cus()) * per_cu;
+    const int grid = static_cast<int>(tiles < cap ? tiles : cap);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WM * WN * 64), lds, stream, a);
+    return pdt_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
+    if (a.zeros == nullptr || (a.bias != nullptr && a.addend != nullptr)) return -1;
+    if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1>(a, stream);
+    if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2>(a, stream);
+    return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0>(a, stream);
+}
+
 // Host entry.  Shapes are validated here; the kernel assumes them.
 //   tile: 0 = 128x128, 1 = 128x64 (narrow N), 2 = 256x128... (see switch)
 // Returns 0 on success, -1 on invalid arguments, otherwise a hipError_t.
@@ -319,7 +618,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             const void* addend, const void* addend_bits, int M, int N,
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
-                            const int* tap_woff, int tile, int smallc, void* stream) {
+                            const int* tap_woff, int tile, int smallc, const void* zeros, void* stream) {
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
     if (smallc && (T == 0 || ldb < (T * C + GG_BK - 1) / GG_BK * GG_BK)) return -1;  // B rows padded to whole K-steps
@@ -332,6 +631,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.bias = bias;
     a.addend = static_cast<const bf16*>(addend);
     a.addend_bits = static_cast<const uint8_t*>(addend_bits);
+    a.zeros = static_cast<const bf16*>(zeros);
     a.M = M; a.N = N; a.ldb = ldb; a.ldo = ldo; a.C = C; a.T = T;
     a.Hin = Hin; a.Win = Win; a.istr = istr;
     a.Hout = Hout; a.Wout = Wout; a.ostr = ostr; a.oph = oph; a.opw = opw;
@@ -355,6 +655,9 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         case 4: return launch_gather_gemm<128, 128, 2, 4>(a, s);  // 8 waves, 64x32 per wave
         case 5: return launch_gather_gemm<128, 64, 4, 2>(a, s);   // 8 waves, 32x32 per wave
         case 6: return launch_gather_gemm<256, 128, 4, 2>(a, s);  // 8 waves, 64x64 per wave
+        // ring variants (persistent, LDS-DMA): need the page of zeros
+        case 10: return launch_gather_gemm_ring<128, 128, 4, 2, 4>(a, s);  // 8 waves, 4 stages
+        case 13: return launch_gather_gemm_ring<256, 128, 4, 2, 3>(a, s);  // 8 waves, 256-row tile
         default: return -1;
     }
 }

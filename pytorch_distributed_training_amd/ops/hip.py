@@ -41,7 +41,7 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
@@ -331,14 +331,34 @@ SHADOWS = ShadowCache()
 # ------------------------------------------------------------------------------------------------
 # GEMM / convolution launch helpers
 # ------------------------------------------------------------------------------------------------
-_TILE_WIDE = int(_os.environ.get("PDT_GEMM_TILE_WIDE", "0"))
+_TILE_WIDE = int(_os.environ.get("PDT_GEMM_TILE_WIDE", "-1"))  # -1: choose per shape
 _TILE_NARROW = int(_os.environ.get("PDT_GEMM_TILE_NARROW", "1"))
+_RING_MIN_TILES = int(_os.environ.get("PDT_GEMM_RING_MIN_TILES", "768"))
+
+
+_ZERO_PAGES: dict = {}
+
+
+def _zero_page(device: torch.device) -> torch.Tensor:
+    """256 bytes of zeros that nothing ever writes: the source of padding rows for the LDS-DMA loaders."""
+    z = _ZERO_PAGES.get(device)
+    if z is None:
+        z = _ZERO_PAGES[device] = torch.zeros(128, dtype=torch.bfloat16, device=device)
+    return z
 
 
 def _pick_tile(m: int, n: int) -> int:
+    """Tile variant of the gather-GEMM kernel for an M x N output.
+
+    0/1/2: one tile per workgroup (128x128, 128x64, 64x64).  13: persistent workgroups streaming 256x128
+    tiles through an LDS-DMA ring; it wins once every CU gets several tiles (measured per layer with
+    bench/conv_bench.py), below that the tail of a partially filled last round costs more than it saves."""
     if n <= 64:
         return _TILE_NARROW if m >= 128 else 2
-    return _TILE_WIDE
+    if _TILE_WIDE >= 0:
+        return _TILE_WIDE
+    tiles = -(-m // 256) * -(-n // 128)
+    return 13 if tiles >= _RING_MIN_TILES else 0
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
@@ -349,7 +369,8 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
-                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc), _stream()),
+                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc),
+                     _zero_page(a.device).data_ptr(), _stream()),
         "gather_gemm",
     )
 

@@ -72,6 +72,29 @@ def test_conv_forward_backward(hip, nb, cin, cout, k, stride, pad, hw):
         assert _rel_err(xb.grad, xr.grad) < 8e-3
 
 
+RING_CASES = [
+    # (batch, cin, cout, k, stride, pad, hw): more 256x128 tiles than CUs, rows and channels that do not
+    # fill the last tile, several taps, strided data gradient
+    (24, 128, 192, 1, 1, 0, 56),
+    (11, 64, 320, 3, 1, 1, 37),
+    (9, 256, 384, 3, 2, 1, 45),
+]
+
+
+@pytest.mark.parametrize("tile", [0, 3, 6, 10, 13])
+@pytest.mark.parametrize("nb,cin,cout,k,stride,pad,hw", RING_CASES)
+def test_conv_every_wide_tile_variant(hip, monkeypatch, tile, nb, cin, cout, k, stride, pad, hw):
+    """Each wide-N kernel variant (one tile per workgroup, and the persistent LDS-DMA ring) on its own."""
+    monkeypatch.setattr(hip, "_TILE_WIDE", tile)
+    test_conv_forward_backward(hip, nb, cin, cout, k, stride, pad, hw)
+
+
+@pytest.mark.parametrize("tile", [10, 13])
+def test_linear_ring_variant_with_bias(hip, monkeypatch, tile):
+    monkeypatch.setattr(hip, "_TILE_WIDE", tile)
+    test_linear_forward_backward(hip, 3000, 256, 1000, True)
+
+
 @pytest.mark.parametrize("m,k,n,bias", [(256, 2048, 1000, True), (64, 512, 10, True), (300, 768, 3072, False), (197 * 4, 768, 768, True)])
 def test_linear_forward_backward(hip, m, k, n, bias):
     torch.manual_seed(1)
