@@ -440,26 +440,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     auto compute = [&](int slot) {
         const bf16* sA = ring + slot * STAGE;
         const bf16* sB = sA + BM * GG_BK;
+        // both 32-deep halves of the K-step have their own fragment registers, so the reads of the second
+        // half are issued under the MFMAs of the first (the schedule is pinned below)
+        bf16x8 fa[2][FM], fb[2][FN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[FM], fb[FN];
             const int kc = kk * 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int row = wm * TM + i * 16 + (lane & 15);
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + row * GG_BK + ((kc ^ (row & 7)) << 3));
-            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int row = wn * TN + j * 16 + (lane & 15);
-                fb[j] = *reinterpret_cast<const bf16x8*>(sB + row * GG_BK + ((kc ^ (row & 7)) << 3));
+                fb[kk][j] = *reinterpret_cast<const bf16x8*>(sB + row * GG_BK + ((kc ^ (row & 7)) << 3));
             }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * TM + i * 16 + (lane & 15);
+                fa[kk][i] = *reinterpret_cast<const bf16x8*>(sA + row * GG_BK + ((kc ^ (row & 7)) << 3));
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        // schedule: first-half reads | (2 MFMA, 1 read) until the second-half reads are out | remaining MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+#pragma unroll
+        for (int r = 0; r < FM + FN; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * FM * FN - 2 * (FM + FN), 0);
     };
 
     // BatchNorm partial sums of this lane's 8 channels, carried across tiles
