@@ -42,6 +42,7 @@ def _sig(name: str, argtypes):
 
 
 _gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp])
+_colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
@@ -157,27 +158,20 @@ def _grad_sink(param: torch.Tensor, phys_shape) -> Optional[torch.Tensor]:
 
 
 def enable_grad_sink(module: nn.Module) -> int:
-    """Allow convolution / linear weight gradients of ``module`` to be accumulated straight into ``.grad``.
+    """Allow the kernels to accumulate parameter gradients of ``module`` straight into ``.grad``.
 
-    Only weights that belong to exactly one ``nn.Conv2d`` / ``nn.Linear`` are enabled: a parameter that also
-    receives gradient through another path (tied embeddings, a regulariser) must go through autograd so
-    the contributions are summed before anyone is told the gradient is complete.  Returns the number of
-    parameters enabled.
+    Every kernel that produces a parameter gradient adds to its destination (atomics into a zeroed buffer),
+    so a parameter that is used several times in one forward (tied embeddings) simply receives several
+    accumulations; autograd runs the parameter's AccumulateGrad node, and with it any gradient-ready hook,
+    only after all of its producers have run, whether they returned a tensor or ``None``.  Gradients from
+    operators without a sink (plain PyTorch ops) still arrive through autograd and are added on top.
+    Returns the number of parameters enabled.
     """
-    owners: Dict[int, int] = {}
-    for m in module.modules():
-        for p in m._parameters.values():
-            if p is not None:
-                owners[id(p)] = owners.get(id(p), 0) + 1
     n = 0
-    for m in module.modules():
-        if isinstance(m, (nn.Conv2d, nn.Linear)) and m.weight is not None and owners.get(id(m.weight), 0) == 1:
-            m.weight._pdt_sink_ok = True
+    for p in module.parameters():
+        if p.requires_grad and p.dtype == torch.float32:
+            p._pdt_sink_ok = True
             n += 1
-        elif isinstance(m, nn.BatchNorm2d) and m.weight is not None and m.bias is not None:
-            if owners.get(id(m.weight), 0) == 1 and owners.get(id(m.bias), 0) == 1:
-                m.weight._pdt_sink_ok = m.bias._pdt_sink_ok = True
-                n += 2
     return n
 
 
@@ -347,6 +341,16 @@ def _zero_page(device: torch.device) -> torch.Tensor:
     return z
 
 
+_NUM_CUS = 0
+
+
+def _num_cus() -> int:
+    global _NUM_CUS
+    if _NUM_CUS == 0:
+        _NUM_CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return _NUM_CUS
+
+
 def _pick_tile(m: int, n: int) -> int:
     """Tile variant of the gather-GEMM kernel for an M x N output.
 
@@ -358,7 +362,11 @@ def _pick_tile(m: int, n: int) -> int:
     if _TILE_WIDE >= 0:
         return _TILE_WIDE
     tiles = -(-m // 256) * -(-n // 128)
-    return 13 if tiles >= _RING_MIN_TILES else 0
+    cus = _num_cus()
+    rounds = -(-tiles // cus)
+    if tiles >= _RING_MIN_TILES or (tiles >= cus and tiles >= 0.9 * rounds * cus):
+        return 13
+    return 0
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
@@ -771,6 +779,7 @@ class _Linear(torch.autograd.Function):
         bias_f = bias.detach() if bias is not None else None
         _launch_gather_gemm(x2, wb, out, None, bias_f, M, n, k, npad, k, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
         ctx.save_for_backward(x2, weight)
+        ctx.bias = bias
         ctx.meta = (lead, n, k, npad, bias is not None)
         res = out[:, :n] if npad != n else out
         return res.reshape(*lead, n) if len(lead) != 1 else res
@@ -804,7 +813,11 @@ class _Linear(torch.autograd.Function):
             if sink is not None:
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
-            db = gp[:, :n].sum(dim=0, dtype=torch.float32)
+            sink = _grad_sink(ctx.bias, (n,))
+            db = sink if sink is not None else torch.zeros(n, dtype=torch.float32, device=g.device)
+            _check(_colsum(gp.data_ptr(), db.data_ptr(), M, n, npad, _stream()), "colsum")
+            if sink is not None:
+                db = None
         return dx, dw, db
 
 

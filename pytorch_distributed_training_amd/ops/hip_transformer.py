@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-from .hip import _check, _lib, _ptr, _stream
+from .hip import _check, _colsum, _grad_sink, _lib, _ptr, _stream
 
 _vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
@@ -30,7 +30,6 @@ _ln_bwd = _sig("pdt_layernorm_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
 _gelu_fwd = _sig("pdt_gelu_fwd", [_vp, _vp, _ll, _vp])
 _gelu_bwd = _sig("pdt_gelu_bwd", [_vp, _vp, _vp, _ll, _vp])
 _bias_res = _sig("pdt_bias_residual", [_vp, _vp, _vp, _vp, _ll, _i, _vp])
-_colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _emb_fwd = _sig("pdt_embedding_fwd", [_vp, _vp, _vp, _ll, _i, _ll, _vp])
 _emb_bwd = _sig("pdt_embedding_bwd", [_vp, _vp, _vp, _ll, _i, _ll, _vp])
 _attn_fwd = _sig("pdt_attention_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp])
@@ -55,6 +54,7 @@ class _LayerNorm(torch.autograd.Function):
         _check(_ln_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                        rows, d, eps, _stream()), "layernorm_fwd")
         ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.bias = bias
         return y
 
     @staticmethod
@@ -64,10 +64,18 @@ class _LayerNorm(torch.autograd.Function):
         d = x.shape[-1]
         rows = x.numel() // d
         dx = torch.empty_like(x)
-        dgb = torch.zeros((2, d), dtype=torch.float32, device=x.device)
+        # the kernel adds its column sums to its destinations: the parameters' .grad when that is allowed
+        sw, sb = _grad_sink(weight, (d,)), _grad_sink(ctx.bias, (d,))
+        if sw is not None and sb is not None:
+            dg, db = sw, sb
+        else:
+            sw = sb = None
+            dg, db = torch.zeros((2, d), dtype=torch.float32, device=x.device).unbind(0)
         _check(_ln_bwd(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                       dgb[0].data_ptr(), dgb[1].data_ptr(), rows, d, _stream()), "layernorm_bwd")
-        return dx, dgb[0], dgb[1], None
+                       dg.data_ptr(), db.data_ptr(), rows, d, _stream()), "layernorm_bwd")
+        if sw is not None:
+            return dx, None, None, None
+        return dx, dg, db, None
 
 
 def layer_norm(x, weight, bias, eps: float = 1e-5):
@@ -105,6 +113,7 @@ class _BiasResidual(torch.autograd.Function):
         out = torch.empty_like(x)
         _check(_bias_res(x.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), x.numel(), d, _stream()), "bias_residual")
         ctx.meta = (bias is not None, residual is not None, d)
+        ctx.bias = bias
         return out
 
     @staticmethod
@@ -114,8 +123,11 @@ class _BiasResidual(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[1]:
             g2 = _bf16c(g)
             rows = g2.numel() // d
-            db = torch.zeros(d, dtype=torch.float32, device=g.device)
+            sink = _grad_sink(ctx.bias, (d,))
+            db = sink if sink is not None else torch.zeros(d, dtype=torch.float32, device=g.device)
             _check(_colsum(g2.data_ptr(), db.data_ptr(), rows, d, d, _stream()), "colsum")
+            if sink is not None:
+                db = None
         return g, db, (g if has_res else None)
 
 
@@ -134,6 +146,7 @@ class _Embedding(torch.autograd.Function):
         out = torch.empty((ids_c.numel(), d), dtype=torch.bfloat16, device=weight.device)
         _check(_emb_fwd(ids_c.data_ptr(), w.data_ptr(), out.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_fwd")
         ctx.save_for_backward(ids_c)
+        ctx.weight = weight
         ctx.meta = (vocab, d)
         return out.reshape(*ids.shape, d)
 
@@ -142,9 +155,10 @@ class _Embedding(torch.autograd.Function):
         (ids_c,) = ctx.saved_tensors
         vocab, d = ctx.meta
         g2 = _bf16c(g).reshape(-1, d)
-        dw = torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
+        sink = _grad_sink(ctx.weight, (vocab, d))  # no [vocab, d] temporary and no dense add when allowed
+        dw = sink if sink is not None else torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
         _check(_emb_bwd(ids_c.data_ptr(), g2.data_ptr(), dw.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_bwd")
-        return None, dw
+        return None, (None if sink is not None else dw)
 
 
 def embedding(ids, weight):

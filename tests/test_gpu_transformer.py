@@ -139,3 +139,32 @@ def test_vit_and_gpt2_tiny_train_on_gpu():
         losses.append(float(l.detach()))
     assert abs(losses[0] - math.log(512)) < 0.7
     assert losses[-1] < 0.85 * losses[0], losses
+
+
+def test_gradient_sinks_match_autograd_accumulation():
+    """Kernels that add parameter gradients straight into ``.grad`` (LayerNorm, biases, embedding, linear
+    weights - including the embedding matrix tied to the output projection) give the same gradients as
+    returning them to autograd."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    dev = _dev()
+    ids = torch.randint(0, 512, (4, 64), device=dev)
+    tg = torch.randint(0, 512, (4, 64), device=dev)
+    grads = {}
+    for sink in (False, True):
+        torch.manual_seed(11)
+        gpt = build_model("gpt2_tiny").to(dev)
+        if sink:
+            assert ops.prepare_module(gpt) is gpt
+            assert all(getattr(p, "_pdt_sink_ok", False) for p in gpt.parameters())
+        opt = FusedOptimizer(gpt.parameters(), mode="adamw", lr=1e-3)
+        opt.zero_grad()  # materialises the flat fp32 gradient buffer the sinks write into
+        gpt(ids, tg).backward()
+        grads[sink] = {n: p.grad.detach().clone() for n, p in gpt.named_parameters()}
+    assert grads[True].keys() == grads[False].keys()
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert torch.isfinite(a).all()
+        assert _rel(a, b) < 2e-3, n
