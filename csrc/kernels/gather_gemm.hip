@@ -686,6 +686,7 @@ struct WgradArgs {
     const bf16* dY;
     const bf16* X;
     float* dW;
+    const bf16* zeros;  // >= 16 bytes of zeros (ring variant)
     int M, N, ldy, C, T, ldw;
     int Hin, Win, istr, OA, OB;
     FastDiv div_ab, div_b, div_c;
@@ -724,13 +725,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (p.N + BT - 1) / BT, tiles_c = (p.C + BT - 1) / BT;
-    int bid = blockIdx.x;
+    // All workgroups of one pixel range (every tile and tap) read the same rows of dY and X: give them
+    // consecutive logical ids and map those to one XCD, so the rows are fetched into that L2 once.
+    const int lin = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    int bid = lin % gridDim.x;
+    const int split = lin / gridDim.x;
     const int ntap = SMALLC ? 1 : p.T;
-    const int tap = bid % ntap;  // taps fastest: neighbouring blocks re-read the same pixels from L2
+    const int tap = bid % ntap;
     bid /= ntap;
     const int tc = bid % tiles_c, tn = bid / tiles_c;
     const int n0 = tn * BT, c0 = tc * BT;
-    const int ms = blockIdx.y * p.m_per_split;
+    const int ms = split * p.m_per_split;
     const int me = min(p.M, ms + p.m_per_split);
     const int dh = SMALLC ? 0 : p.tap_dh[tap], dw = SMALLC ? 0 : p.tap_dw[tap];
 
@@ -868,10 +873,193 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant of the weight gradient: both operand tiles ([64 pixels][BN] of dY and [64 pixels][BC]
+// of the gathered input) are filled by LDS-DMA into a ring of NS stages, NS - 2 of which stay in flight
+// across the one barrier of a K-step (see gather_gemm_ring_kernel for the protocol).  Rows are not padded
+// (an LDS-DMA instruction writes 1 KB linearly); instead the 32-byte units of a row are XOR-ed with
+// row & 7, applied to the per-lane source address and again by the transposed fragment reads: the 8
+// consecutive rows a 32-lane half of `ds_read_b64_tr_b16` touches then fall on 8 distinct bank groups.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int BC, int WN, int WC, int NS>
+__global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
+    constexpr int KM = 64;                       // pixels per K-step
+    constexpr int NW = WN * WC;
+    constexpr int TN = BN / WN, TC = BC / WC;    // per-wave tile
+    constexpr int FN = TN / 16, FC = TC / 16;
+    constexpr int YCH = BN / 8, XCH = BC / 8;    // 16-byte chunks per row
+    constexpr int YR = 64 / YCH, XR = 64 / XCH;  // rows per 1 KB DMA piece
+    constexpr int YI = (KM / YR) / NW, XI = (KM / XR) / NW;  // pieces per wave and stage
+    constexpr int LPW = YI + XI;
+    constexpr int STAGE = KM * (BN + BC);        // elements: [Y tile | X tile]
+    static_assert((KM / YR) % NW == 0 && (KM / XR) % NW == 0, "whole DMA pieces per wave");
+    static_assert(NS >= 3 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
+    static_assert(YR <= 8 && XR <= 8 && BN >= 128 && BC >= 128, "rows of at least 256 bytes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* ring = reinterpret_cast<bf16*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int tiles_c = (p.C + BC - 1) / BC;
+    // workgroups of one pixel range share their operand rows: consecutive logical ids, one XCD (see wgrad_kernel)
+    const int lin = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    int bid = lin % gridDim.x;
+    const int split = lin / gridDim.x;
+    const int tap = bid % p.T;
+    bid /= p.T;
+    const int tc = bid % tiles_c, tn = bid / tiles_c;
+    const int n0 = tn * BN, c0 = tc * BC;
+    const int ms = split * p.m_per_split;
+    const int me = min(p.M, ms + p.m_per_split);
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const int nsteps = (me - ms + KM - 1) / KM;
+
+    // loader: lane -> (row inside a piece, physical chunk); the logical chunk it fetches undoes the swizzle.
+    // Pieces start at multiples of YR / XR rows, so row & 7 is known per piece.
+    const int y_lr = lane / YCH, y_pc = lane % YCH;
+    const int x_lr = lane / XCH, x_pc = lane % XCH;
+    int ld_issued = 0, ld_slot = 0;
+    auto issue_stage = [&]() {
+        const int mbase = ms + ld_issued * KM;
+        bf16* sY = ring + ld_slot * STAGE;
+        bf16* sX = sY + KM * BN;
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            const int row = (wave * YI + i) * YR + y_lr;
+            const int c = ((((y_pc >> 1) ^ (row & 7)) << 1) | (y_pc & 1)) * 8;
+            const int m = mbase + row;
+            const bool ok = m < me && n0 + c < p.N;
+            const bf16* src = ok ? p.dY + static_cast<size_t>(m) * p.ldy + n0 + c : p.zeros;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sY + (wave * YI + i) * YR * BN), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * XR + x_lr;
+            const int c = ((((x_pc >> 1) ^ (row & 7)) << 1) | (x_pc & 1)) * 8;
+            const int m = mbase + row;
+            bool ok = m < me && c0 + c < p.C;
+            uint32_t off = 0;
+            if (ok) {
+                const uint32_t img = fastdiv(m, p.div_ab);
+                const uint32_t rem = m - img * (p.OA * p.OB);
+                const uint32_t a = fastdiv(rem, p.div_b);
+                const uint32_t b = rem - a * p.OB;
+                const int ih = static_cast<int>(a) * p.istr + dh, iw = static_cast<int>(b) * p.istr + dw;
+                ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                     static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+                off = (img * (p.Hin * p.Win) + ih * p.Win + iw) * p.C + c0 + c;
+            }
+            const bf16* src = ok ? p.X + off : p.zeros;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sX + (wave * XI + i) * XR * BC), 16, 0, 0);
+        }
+        ++ld_issued;
+        ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
+    };
+
+    f32x4 acc[FN][FC];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed fragment addressing as in wgrad_kernel: lane (16g + 4q + pp) supplies block row q, columns
+    // 4pp..4pp+3; lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3 of each 32-row sub-step.
+    // The reads are inline assembly: through the builtin the compiler cannot tell them from the pending
+    // LDS-DMA writes and drains the whole DMA queue (vmcnt(0)) in front of every K-step.  Their completion
+    // is therefore awaited by hand (lgkmcnt(0), then a scheduling fence so no MFMA is hoisted above it).
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_void_t*)ring));
+    auto compute = [&](int slot) {
+        const uint32_t yb = lds_base + static_cast<uint32_t>(slot * STAGE) * 2u;
+        const uint32_t xb = yb + KM * BN * 2u;
+        s16x4 ylo[2][FN], yhi[2][FN], xlo[2][FC], xhi[2][FC];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int krow = kk * 32 + 4 * g + q;  // krow and krow + 16 have the same row & 7
+            const int sw = krow & 7;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int u = (wr * TN + i * 16) >> 4;
+                const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ sw) << 4) + 4 * pp) * 2u;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[kk][i]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[kk][i]) : "v"(a), "n"(16 * BN * 2) : "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < FC; ++j) {
+                const int u = (wc * TC + j * 16) >> 4;
+                const uint32_t a = xb + static_cast<uint32_t>(krow * BC + ((u ^ sw) << 4) + 4 * pp) * 2u;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kk][j]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[kk][j]) : "v"(a), "n"(16 * BC * 2) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const s16x8 yv = {ylo[kk][i][0], ylo[kk][i][1], ylo[kk][i][2], ylo[kk][i][3],
+                                  yhi[kk][i][0], yhi[kk][i][1], yhi[kk][i][2], yhi[kk][i][3]};
+#pragma unroll
+                for (int j = 0; j < FC; ++j) {
+                    const s16x8 xv = {xlo[kk][j][0], xlo[kk][j][1], xlo[kk][j][2], xlo[kk][j][3],
+                                      xhi[kk][j][0], xhi[kk][j][1], xhi[kk][j][2], xhi[kk][j][3]};
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
+                                                                         acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (ld_issued < nsteps) issue_stage();
+    int slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if (ld_issued - (s + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
+        else wait_vm_and_barrier<0>();
+        if (ld_issued < nsteps) issue_stage();
+        compute(slot);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+
+    // D[i = n][j = c]: lane holds rows (lane>>4)*4 + e, column lane&15
+    const int woff = p.tap_woff[tap];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FC; ++j) {
+            const int c = c0 + wc * TC + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wr * TN + i * 16 + (lane >> 4) * 4 + e;
+                if (n < p.N && c < p.C)
+                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(n) * p.ldw + woff + c, acc[i][j][e],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+}
+
+template <int BN, int BC, int WN, int WC, int NS>
+static int launch_wgrad_ring(const WgradArgs& a, int gy, hipStream_t stream) {
+    constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16);
+    static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
+    if (a.zeros == nullptr) return -1;
+    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS>;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured = true;
+    }
+    const int gx = pdt_cdiv(a.N, BN) * pdt_cdiv(a.C, BC) * a.T;
+    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(WN * WC * 64), lds, stream, a);
+    return pdt_launch_status();
+}
+
 // dW must be zero (or hold a value to accumulate onto) before the call.
 PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
                       int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
-                      int splits, int tile, int smallc, void* stream) {
+                      int splits, int tile, int smallc, const void* zeros, void* stream) {
     // rows of dY are read in 8-column chunks: ldy must cover N rounded up to 8 (columns >= N are ignored)
     if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8) return -1;
     if (!smallc && (C % 8) != 0) return -1;
@@ -880,6 +1068,7 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.dY = static_cast<const bf16*>(dY);
     a.X = static_cast<const bf16*>(X);
     a.dW = dW;
+    a.zeros = static_cast<const bf16*>(zeros);
     a.M = M; a.N = N; a.ldy = ldy; a.C = C; a.T = T; a.ldw = ldw;
     a.Hin = Hin; a.Win = Win; a.istr = istr; a.OA = OA; a.OB = OB;
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
@@ -918,6 +1107,12 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         const int gx = pdt_cdiv(N, BT) * pdt_cdiv(C, BT) * T;
         const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
         hipLaunchKernelGGL((wgrad_kernel<BT, false>), dim3(gx, gy), dim3(256), lds, s, a);
+    } else if (tile == 10) {
+        return launch_wgrad_ring<128, 128, 2, 4, 4>(a, gy, s);
+    } else if (tile == 11) {
+        return launch_wgrad_ring<256, 128, 4, 2, 3>(a, gy, s);
+    } else if (tile == 12) {
+        return launch_wgrad_ring<128, 256, 2, 4, 3>(a, gy, s);
     } else {
         return -1;
     }

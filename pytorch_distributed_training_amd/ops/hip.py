@@ -43,7 +43,7 @@ def _sig(name: str, argtypes):
 
 _gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
-_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp])
+_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
@@ -388,30 +388,44 @@ WGRAD_ATOMIC_CAP_MB = int(_os.environ.get("PDT_WGRAD_ATOMIC_CAP_MB", "8"))
 WGRAD_MIN_BLOCKS = int(_os.environ.get("PDT_WGRAD_MIN_BLOCKS", "384"))
 
 
-def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bt: int) -> int:
+WGRAD_RING = int(_os.environ.get("PDT_WGRAD_RING", "1"))  # 0: one-step register-staged kernel everywhere
+WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "512"))
+
+
+def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int] = None, target: Optional[int] = None) -> int:
     """How many ways to split the pixel reduction across workgroups.
 
     More splits fill the chip when the weight tile count is small, but every split adds one fp32 atomic
     pass over the whole weight gradient (global float atomics run at roughly a quarter of the store rate),
     so the atomic volume is capped."""
-    tiles = math.ceil(N / bt) * math.ceil(C / bt) * ntaps
-    want = max(1, WGRAD_TARGET_BLOCKS // max(tiles, 1))
+    tiles = math.ceil(N / bn) * math.ceil(C / (bc or bn)) * ntaps
+    target = target or WGRAD_TARGET_BLOCKS
+    want = max(1, target // max(tiles, 1))
     weight_bytes = 4 * N * C * ntaps
     cap = max(1, (WGRAD_ATOMIC_CAP_MB << 20) // max(weight_bytes, 1))
-    floor = min(want, math.ceil(WGRAD_MIN_BLOCKS / max(tiles, 1)))
+    floor = min(want, math.ceil(min(WGRAD_MIN_BLOCKS, target) / max(tiles, 1)))
     return max(1, min(max(min(want, cap), floor), M // 256))
 
 
 def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=False) -> None:
-    tile = 0 if (N > 64 and C > 64 and not smallc) else 1
-    bt = 128 if tile == 0 else 64
-    splits = _wgrad_splits(M, N, C * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
+    if WGRAD_RING and not smallc and N >= 128 and C >= 128:
+        # LDS-DMA ring kernel, one workgroup of 8 waves per CU; the 256-wide side goes to the larger dimension
+        if WGRAD_RING >= 10:
+            tile = WGRAD_RING
+        else:
+            tile = 11 if N >= 256 and N >= C else (12 if C >= 256 else 10)
+        bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256)}[tile]
+        splits = _wgrad_splits(M, N, C, len(taps), bn, bc, WGRAD_RING_TARGET_BLOCKS)
+    else:
+        tile = 0 if (N > 64 and C > 64 and not smallc) else 1
+        bt = 128 if tile == 0 else 64
+        splits = _wgrad_splits(M, N, C * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
     dh = _int_array([t[0] for t in taps])
     dwi = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
     _check(
         _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
-               wo, splits, tile, int(smallc), _stream()),
+               wo, splits, tile, int(smallc), _zero_page(dy.device).data_ptr(), _stream()),
         "wgrad",
     )
 
