@@ -54,6 +54,7 @@ def main():
         return F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(b, s_, d)
 
     ops.attention_qkv = sdpa_qkv
+    ops.residual_link = lambda x: None
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)

@@ -33,8 +33,12 @@ struct OptHyper {
     int first_step;
 };
 
+// hp != nullptr: hyper-parameters are read from device memory (written by set_hyper_kernel before every
+// launch), so a launch recorded in a hipGraph picks up the current learning rate and bias corrections.
 __global__ __launch_bounds__(256) void multi_tensor_step_kernel(const PdtTensorDesc* __restrict__ descs,
-                                                               const PdtChunk* __restrict__ chunks, const OptHyper h) {
+                                                               const PdtChunk* __restrict__ chunks, const OptHyper hv,
+                                                               const OptHyper* __restrict__ hp) {
+    const OptHyper h = hp != nullptr ? *hp : hv;
     const PdtChunk ck = chunks[blockIdx.x];
     const PdtTensorDesc d = descs[ck.tensor];
     const long long end = min(d.n, ck.start + PDT_OPT_CHUNK);
@@ -108,6 +112,40 @@ PDT_API int pdt_multi_tensor_step(const void* descs, const void* chunks, int n_c
     h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.wd = wd; h.bc1 = bc1; h.bc2_sqrt = bc2_sqrt;
     h.momentum = momentum; h.grad_scale = grad_scale; h.mode = mode; h.first_step = first_step;
     hipLaunchKernelGGL(multi_tensor_step_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const PdtTensorDesc*>(descs), static_cast<const PdtChunk*>(chunks), h);
+                       static_cast<const PdtTensorDesc*>(descs), static_cast<const PdtChunk*>(chunks), h,
+                       static_cast<const OptHyper*>(nullptr));
+    return pdt_launch_status();
+}
+
+__global__ void set_hyper_kernel(OptHyper* dst, const OptHyper h) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // field-wise vector stores from one lane
+        dst->lr = h.lr; dst->beta1 = h.beta1; dst->beta2 = h.beta2; dst->eps = h.eps; dst->wd = h.wd;
+        dst->bc1 = h.bc1; dst->bc2_sqrt = h.bc2_sqrt; dst->momentum = h.momentum; dst->grad_scale = h.grad_scale;
+        dst->mode = h.mode; dst->first_step = h.first_step;
+    }
+}
+
+PDT_API int pdt_opt_hyper_bytes() { return static_cast<int>(sizeof(OptHyper)); }
+
+// Stream-ordered update of a device-resident hyper-parameter block (the values travel as kernel arguments,
+// so there is no host buffer whose lifetime the caller would have to manage).
+PDT_API int pdt_opt_set_hyper(void* dst, int mode, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                              float bc2_sqrt, float momentum, float grad_scale, int first_step, void* stream) {
+    if (dst == nullptr || mode < 0 || mode > 2) return -1;
+    OptHyper h;
+    h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.wd = wd; h.bc1 = bc1; h.bc2_sqrt = bc2_sqrt;
+    h.momentum = momentum; h.grad_scale = grad_scale; h.mode = mode; h.first_step = first_step;
+    hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<OptHyper*>(dst), h);
+    return pdt_launch_status();
+}
+
+// The step with hyper-parameters taken from `hyper` (device memory, see pdt_opt_set_hyper).
+PDT_API int pdt_multi_tensor_step_dev(const void* descs, const void* chunks, int n_chunks, const void* hyper, void* stream) {
+    if (n_chunks <= 0 || hyper == nullptr) return -1;
+    OptHyper unused = {};
+    hipLaunchKernelGGL(multi_tensor_step_kernel, dim3(n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PdtTensorDesc*>(descs), static_cast<const PdtChunk*>(chunks), unused,
+                       static_cast<const OptHyper*>(hyper));
     return pdt_launch_status();
 }

@@ -60,6 +60,9 @@ from .train import TrainConfig, run_training
 @click.option("--dist-timeout-s", type=float, default=600.0, show_default=True)
 @click.option("--profile", type=str, default="", help="write a chrome trace of host-side phases to this path")
 @click.option("--check-finite", is_flag=True, default=False)
+@click.option("--hip-graph", is_flag=True, default=False,
+              help="record the whole training step into a hipGraph after --graph-after eager steps (launch-bound configs)")
+@click.option("--graph-after", type=int, default=3, show_default=True)
 def main(**kwargs):
     cfg = TrainConfig(**kwargs)
     run_training(cfg)

@@ -60,6 +60,8 @@ _im2col = _sig("pdt_im2col", [_vp, _vp] + [_i] * 9 + [_vp])
 _cast_pad = _sig("pdt_cast_pad_f32_bf16", [_vp, _vp, _ll, _i, _i, _vp])
 _transpose_w = _sig("pdt_transpose_w", [_vp, _vp, _i, _i, _i, _vp])
 _mt_step = _sig("pdt_multi_tensor_step", [_vp, _vp, _i, _i] + [_f] * 9 + [_i, _vp])
+_mt_step_dev = _sig("pdt_multi_tensor_step_dev", [_vp, _vp, _i, _vp, _vp])
+_opt_set_hyper = _sig("pdt_opt_set_hyper", [_vp, _i] + [_f] * 9 + [_i, _vp])
 _lib.pdt_opt_chunk_elems.restype = ctypes.c_int
 _lib.pdt_opt_desc_bytes.restype = ctypes.c_int
 _lib.pdt_opt_chunk_bytes.restype = ctypes.c_int
@@ -948,17 +950,37 @@ def _span_bytes(t: torch.Tensor) -> int:
 _MODE = {"adam": 0, "adamw": 1, "sgd": 2}
 
 
-def multi_tensor_step(plan: MultiTensorPlan, group) -> None:
+def _hyper_args(group):
     t = group["step"]
     b1, b2 = group["betas"]
     bc1 = 1.0 - b1 ** t
     bc2s = math.sqrt(1.0 - b2 ** t)
-    _check(
-        _mt_step(plan.desc.data_ptr(), plan.chunks.data_ptr(), plan.n_chunks, _MODE[group["mode"]], group["lr"], b1, b2,
-                 group["eps"], group["weight_decay"], bc1, bc2s, group["momentum"], group["grad_scale"],
-                 1 if t == 1 else 0, _stream()),
-        "multi_tensor_step",
-    )
+    return (group["lr"], b1, b2, group["eps"], group["weight_decay"], bc1, bc2s, group["momentum"], group["grad_scale"],
+            1 if t == 1 else 0)
+
+
+def new_hyper_block(device) -> torch.Tensor:
+    """Device memory for one parameter group's hyper-parameters (see :func:`upload_hyper`)."""
+    return torch.zeros(_lib.pdt_opt_hyper_bytes(), dtype=torch.uint8, device=device)
+
+
+def upload_hyper(block: torch.Tensor, group) -> None:
+    """Stream-ordered write of the group's current hyper-parameters (learning rate, bias corrections for
+    ``group["step"]`` ...) into ``block``; a captured optimizer launch reads them from there."""
+    _check(_opt_set_hyper(block.data_ptr(), _MODE[group["mode"]], *_hyper_args(group), _stream()), "opt_set_hyper")
+
+
+def multi_tensor_step(plan: MultiTensorPlan, group, hyper_block: Optional[torch.Tensor] = None) -> None:
+    if hyper_block is not None:
+        _check(_mt_step_dev(plan.desc.data_ptr(), plan.chunks.data_ptr(), plan.n_chunks, hyper_block.data_ptr(), _stream()),
+               "multi_tensor_step")
+    else:
+        lr, b1, b2, eps, wd, bc1, bc2s, mom, gs, first = _hyper_args(group)
+        _check(
+            _mt_step(plan.desc.data_ptr(), plan.chunks.data_ptr(), plan.n_chunks, _MODE[group["mode"]], lr, b1, b2, eps, wd,
+                     bc1, bc2s, mom, gs, first, _stream()),
+            "multi_tensor_step",
+        )
     SHADOWS.epoch += 1
     for p in plan.shadow_params:
         SHADOWS.mark_refreshed(p)

@@ -32,7 +32,7 @@ def batch_norm(y: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     )
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0):
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None):
     return F.conv2d(x, weight, None, stride, padding), None
 
 
@@ -45,7 +45,7 @@ def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int
     return F.conv2d(F.relu(batch_norm(y_prev, bn)), weight, None, stride, padding), None
 
 
-def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None):
+def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):
     z = batch_norm(y, bn)
     if id_bn is not None:
         identity = batch_norm(identity, id_bn)

@@ -44,6 +44,8 @@ class FusedOptimizer(Optimizer):
         super().__init__(params, defaults)
         self._plans: Dict[int, object] = {}  # per param-group GPU launch plans
         self._flat_grads: Dict[int, tuple] = {}  # per param-group (flat gradient buffer, view pointers)
+        self._hyper_blocks: Dict[int, torch.Tensor] = {}  # capturable mode: device-resident hyper-parameters
+        self.capturable = False
 
     # ------------------------------------------------------------------ state
     def _init_state(self, group) -> None:
@@ -59,21 +61,62 @@ class FusedOptimizer(Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         group.setdefault("step", 0)
 
+    # ------------------------------------------------------------------ hipGraph support
+    def set_capturable(self, on: bool = True) -> None:
+        """Make ``step()`` recordable in a hipGraph (GPU groups only).
+
+        A recorded kernel launch replays with the argument values of capture time, which would freeze the
+        learning rate and Adam's bias corrections.  In capturable mode those live in a small device block per
+        group: :meth:`advance` (outside the graph, before every replay) bumps the step count and writes the
+        current values with a stream-ordered kernel; ``step()`` inside a capture only records the update
+        kernel, which reads the block.  Outside a capture ``step()`` does both, so eager use is unchanged."""
+        self.capturable = bool(on)
+        if self.capturable:
+            from ..ops import hip
+
+            for gi, group in enumerate(self.param_groups):
+                params = [p for p in group["params"] if p.requires_grad]
+                if params and params[0].is_cuda and gi not in self._hyper_blocks:
+                    self._hyper_blocks[gi] = hip.new_hyper_block(params[0].device)
+
+    def advance(self) -> None:
+        """Capturable mode: count one step and publish its hyper-parameters to the device."""
+        from ..ops import hip
+
+        for gi, group in enumerate(self.param_groups):
+            self._init_state(group)
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params or not params[0].is_cuda:
+                continue
+            group["step"] += 1
+            block = self._hyper_blocks.get(gi)
+            if block is None:
+                block = self._hyper_blocks[gi] = hip.new_hyper_block(params[0].device)
+            hip.upload_hyper(block, group)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        capturing = self.capturable and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if self.capturable and not capturing:
+            self.advance()
         for gi, group in enumerate(self.param_groups):
             self._init_state(group)
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            group["step"] += 1
             if params[0].is_cuda:
+                if not self.capturable:
+                    group["step"] += 1
+                elif capturing and self._plans.get(gi) is None:
+                    raise RuntimeError("capturable optimizer: run at least one eager step before capturing "
+                                       "(the launch plan is built with host-to-device copies)")
                 self._step_hip(gi, group, params)
             else:
+                group["step"] += 1
                 self._step_foreach(group, params)
         return loss
 
@@ -130,7 +173,7 @@ class FusedOptimizer(Optimizer):
             )
             plan = hip.MultiTensorPlan(params, states)
             self._plans[gi] = plan
-        hip.multi_tensor_step(plan, group)
+        hip.multi_tensor_step(plan, group, self._hyper_blocks.get(gi) if self.capturable else None)
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Zero the gradients in place (the default keeps ``.grad`` allocated: kernels accumulate into it).

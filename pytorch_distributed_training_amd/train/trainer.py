@@ -82,6 +82,8 @@ class TrainConfig:
     dist_timeout_s: float = 600.0
     profile: str = ""  # path of a chrome trace with per-phase host spans
     check_finite: bool = False
+    hip_graph: bool = False  # record the whole step into a hipGraph after a few eager steps (GPU only)
+    graph_after: int = 3  # eager steps before the capture
 
 
 @dataclass
@@ -146,7 +148,9 @@ class Trainer:
         self.raw_model = ops.prepare_module(model)
         if self.env.distributed:
             model = wrap_data_parallel(
-                model, self.env, cfg.bucket_mb, cfg.first_bucket_mb, cfg.sync_buffers, cfg.native_rccl
+                model, self.env, cfg.bucket_mb, cfg.first_bucket_mb,
+                cfg.sync_buffers and not cfg.hip_graph,  # the per-step buffer broadcast is not part of a recorded step
+                cfg.native_rccl,
             )
         self.model = model
         # contract line 2 (main.py:59)
@@ -165,6 +169,15 @@ class Trainer:
         self.timer = StepTimer(self.device, enabled=bool(cfg.profile))
         self.trace = ChromeTrace(self.env.rank) if cfg.profile else None
         self.stopper = GracefulStop()
+        self._graph = None
+        self._eager_steps = 0
+        self._use_graph = bool(cfg.hip_graph) and self.device.type == "cuda"
+        if cfg.hip_graph and not self._use_graph:
+            rank_zero_print("--hip-graph ignored: not running on a GPU")
+        if self._use_graph and (cfg.grad_accum > 1 or cfg.profile):
+            raise ValueError("--hip-graph records whole steps: it cannot be combined with --grad-accum > 1 or --profile")
+        if self._use_graph:
+            self.optimizer.set_capturable(True)
 
     # ------------------------------------------------------------------ data
     def _make_loader(self):
@@ -208,9 +221,43 @@ class Trainer:
         else:
             self.optimizer.zero_grad(set_to_none=False)
 
+    def _device_batch(self, batch):
+        """The batch as device tensors in the form the model consumes (inputs of a recorded step)."""
+        if self.kind == "lm":
+            ids, targets = batch
+            return ids.to(self.device), targets.to(self.device)
+        imgs, lbls = batch
+        if imgs.device != self.device or imgs.dtype != self.dtype:
+            imgs = prepare_image_batch(imgs, self.device, self.dtype)
+        return imgs, lbls.to(self.device)
+
+    def _graph_body(self, a, b) -> torch.Tensor:
+        loss = self._forward_loss((a, b))
+        loss.backward()
+        self.optimizer.step()
+        self._zero_grad()
+        return loss.detach()
+
+    def _graphed_train_step(self, batch) -> torch.Tensor:
+        """Eager for the first ``graph_after`` steps, then one hipGraph replay per batch of the recorded shape."""
+        from .graph import GraphedStep
+
+        inputs = self._device_batch(batch)
+        if self._graph is None:
+            self._eager_steps += 1
+            if self._eager_steps <= self.cfg.graph_after:
+                return self._graph_body(*inputs)
+            self._graph = GraphedStep(self._graph_body, self.optimizer, inputs)
+            rank_zero_print(f"hipGraph: recorded the training step after {self.cfg.graph_after} eager steps")
+        if self._graph.matches(inputs):
+            return self._graph(*inputs)
+        return self._graph_body(*inputs)
+
     def train_step(self, batch, accumulate: bool = False) -> torch.Tensor:
         """forward + backward (+ optimizer step unless ``accumulate``); returns the detached loss."""
         cfg = self.cfg
+        if self._use_graph:
+            return self._graphed_train_step(batch)
         span = self.trace.span if self.trace else None
         sync_ctx = self.model.no_sync() if (accumulate and hasattr(self.model, "no_sync")) else _null()
         with sync_ctx:

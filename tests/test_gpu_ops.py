@@ -345,3 +345,96 @@ def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypa
     blk(xb).backward(g)
     assert _rel_err(xa.grad, xb.grad) < 4e-3  # one bf16 rounding apart (sum rounded once vs twice)
     assert _rel_err(wa, blk.conv1.weight.grad) < 1e-6
+
+
+def test_recorded_step_matches_eager_training():
+    """A hipGraph replay of the whole step (zero-grad, forward, backward, Adam update with device-resident
+    hyper-parameters) does what the eager step does.  The first replayed step starts from bit-identical
+    state and must agree tightly; later steps only loosely (fp32 atomics make summation order vary, and
+    a batch-16 BatchNorm network amplifies last-bit differences quickly)."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+    from pytorch_distributed_training_amd.train.graph import GraphedStep
+
+    dev = _dev()
+    torch.manual_seed(5)
+    xs = [ops.to_device_layout(torch.randn(16, 3, 32, 32, device=dev)) for _ in range(6)]
+    ys = [torch.randint(0, 10, (16,), device=dev) for _ in range(6)]
+
+    def run(graphed: bool):
+        torch.manual_seed(6)
+        model = ops.prepare_module(build_model("resnet18", 10, 32).to(dev).to(memory_format=torch.channels_last))
+        opt = FusedOptimizer(model.parameters(), mode="adam", lr=1e-3, weight_decay=1e-3)
+        opt.zero_grad()
+
+        def body(x, y):
+            loss = ops.softmax_cross_entropy(model(x), y)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            return loss.detach()
+
+        losses, snap = [], None
+        step = None
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            if graphed and i == 2:
+                step = GraphedStep(body, opt, (x, y))
+            losses.append(float(step(x, y) if step is not None else body(x, y)))
+            if i == 2:
+                snap = [p.detach().clone() for p in model.parameters()]
+        assert opt.param_groups[0]["step"] == len(xs)
+        if graphed:
+            assert step.replays == len(xs) - 2
+        return losses, snap
+
+    def rel(pa, pb):
+        num = sum(float((a - b).norm() ** 2) for a, b in zip(pa, pb)) ** 0.5
+        return num / sum(float(a.norm() ** 2) for a in pa) ** 0.5
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    assert all(math.isfinite(v) for v in lg)
+    assert le[:3] == pytest.approx(lg[:3], abs=1e-4)   # identical state up to and including the first replay
+    assert rel(pe, pg) < 1e-3                            # ... and the same Adam update (third step: bias corrections)
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 0.3, (le, lg)
+
+
+def test_no_kernel_reads_memory_it_did_not_write(monkeypatch):
+    """Every ``torch.empty`` buffer handed to a kernel is poisoned with NaN: a read of memory that the kernels
+    did not write themselves (a padding column, a pixel no launch covers) surfaces as a non-finite loss or
+    gradient instead of depending on what the allocator recycled."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def poison(t):
+        if t.is_cuda and t.dtype in (torch.float32, torch.bfloat16):
+            t.fill_(float("nan"))
+        elif t.is_cuda and t.dtype == torch.uint8:
+            t.fill_(255)
+        return t
+
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: poison(real_empty(*a, **k)))
+    monkeypatch.setattr(torch, "empty_like", lambda *a, **k: poison(real_empty_like(*a, **k)))
+    dev = _dev()
+    torch.manual_seed(8)
+    for name, shape, ncls in (("resnet18", (16, 3, 32, 32), 10), ("resnet50", (5, 3, 75, 75), 37)):
+        model = ops.prepare_module(build_model(name, ncls, shape[-1]).to(dev).to(memory_format=torch.channels_last))
+        x = ops.to_device_layout(torch.randn(*shape, device=dev))
+        loss = ops.softmax_cross_entropy(model(x), torch.randint(0, ncls, (shape[0],), device=dev))
+        loss.backward()
+        assert math.isfinite(float(loss.detach()))
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters()), name
+    for name in ("vit_tiny", "gpt2_tiny"):
+        model = ops.prepare_module(build_model(name).to(dev))
+        if name == "vit_tiny":
+            x = ops.to_device_layout(torch.randn(6, 3, 32, 32, device=dev))
+            loss = ops.softmax_cross_entropy(model(x), torch.randint(0, 10, (6,), device=dev))
+        else:
+            ids = torch.randint(0, 512, (3, 50), device=dev)
+            loss = model(ids, ids)
+        loss.backward()
+        assert math.isfinite(float(loss.detach()))
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters()), name
