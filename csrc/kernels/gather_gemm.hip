@@ -41,16 +41,19 @@ struct GatherGemmArgs {
     int Hout, Wout, ostr, oph, opw;
     FastDiv div_ab;  // divide by OA*OB
     FastDiv div_b;   // divide by OB
-    FastDiv div_c;   // divide by C (few-channel mode)
+    int tw;          // packed-row mode: elements per kernel row (32 or 64)
     int OA, OB;
     int tap_dh[GG_MAX_TAPS];
     int tap_dw[GG_MAX_TAPS];
     int tap_woff[GG_MAX_TAPS];
 };
 
-// SMALLC: few input channels (the 3-channel stem).  The reduction index k = tap*C + c is decoded per element
-// and the operand is gathered with 2-byte loads (the whole image batch is cache resident); B rows hold the
-// weights in (tap, c) order zero-padded to a multiple of 64.  No patch matrix is materialised.
+// SMALLC: few input channels (the 3-channel stem), "packed rows".  The input has been copied into a
+// zero-bordered image with the channels padded to C (4 or 8) elements per pixel, so one kernel row of an
+// output pixel is `tw` (32 or 64) contiguous elements starting at pixel (a*istr + kh, b*istr): a K-step of
+// 64 covers 64 / tw kernel rows, every operand chunk is one bounds-check-free 16-byte load, and no patch
+// matrix is materialised.  B rows hold the weights as [kh][tw] with zeros at the positions that correspond
+// to padding channels, to pixels beyond the kernel width and to kernel rows >= T.
 template <int BM, int BN, int WM, int WN, bool SMALLC>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherGemmArgs p) {
     constexpr int NT = WM * WN * 64;           // threads per workgroup (4 or 8 waves)
@@ -109,34 +112,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int csteps = p.C / GG_BK;
-    const int nsteps = SMALLC ? (p.T * p.C + GG_BK - 1) / GG_BK : p.T * csteps;
+    const int nsteps = SMALLC ? (p.T * p.tw + GG_BK - 1) / GG_BK : p.T * csteps;
     bf16x8 ra[AP], rb[BP];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     auto load_step = [&](int t, int c0) {
         if (SMALLC) {
-            // here t is the K-step index: this thread's 8 reduction indices are k0 .. k0+7
-            const int k0 = t * GG_BK + chunk * 8;
-            int e_dh[8], e_dw[8], e_c[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + e;
-                const int tap = min(static_cast<int>(fastdiv(k, p.div_c)), p.T - 1);
-                e_c[e] = k - tap * p.C;
-                const bool kv = k < p.T * p.C;
-                e_dh[e] = kv ? p.tap_dh[tap] : -(1 << 24);
-                e_dw[e] = p.tap_dw[tap];
-            }
+            // here t is the K-step index
+            const int cpr = p.tw >> 3;  // 16-byte chunks per kernel row (4 or 8)
+            const int kh = min(t * (8 / cpr) + chunk / cpr, p.T - 1);  // rows >= T have zero weights: any valid row will do
+            const int piece = chunk % cpr;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ih = a_h[i] + e_dh[e], iw = a_w[i] + e_dw[e];
-                    const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
-                                    static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
-                    const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.C + e_c[e];
-                    ra[i][e] = ok ? p.A[off] : static_cast<bf16>(0.f);
-                }
+                const uint32_t off = static_cast<uint32_t>(a_pix[i] + (a_h[i] + kh) * p.Win + a_w[i]) * p.C + piece * 8;
+                ra[i] = a_h[i] >= 0 ? *reinterpret_cast<const bf16x8*>(p.A + off) : zero8;
             }
 #pragma unroll
             for (int i = 0; i < BP; ++i)
@@ -633,7 +622,9 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             const int* tap_woff, int tile, int smallc, const void* zeros, void* stream) {
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
-    if (smallc && (T == 0 || ldb < (T * C + GG_BK - 1) / GG_BK * GG_BK)) return -1;  // B rows padded to whole K-steps
+    // packed rows: `smallc` is the row width tw; pixels are C (4 or 8) elements apart; B rows cover whole K-steps
+    if (smallc && (T == 0 || (smallc != 32 && smallc != 64) || (C != 4 && C != 8) || ldb < (T * smallc + GG_BK - 1) / GG_BK * GG_BK))
+        return -1;
     if ((ldo % 8) != 0 || (ldb % 8) != 0 || OA <= 0 || OB <= 0) return -1;
     GatherGemmArgs a;
     a.A = static_cast<const bf16*>(A);
@@ -650,7 +641,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.OA = OA; a.OB = OB;
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
     a.div_b = make_fastdiv(OB);
-    a.div_c = make_fastdiv(C);
+    a.tw = smallc;
     for (int t = 0; t < T; ++t) {
         if (!smallc && (tap_woff[t] % 8) != 0) return -1;
         a.tap_dh[t] = tap_dh[t];
@@ -689,9 +680,9 @@ struct WgradArgs {
     const bf16* zeros;  // >= 16 bytes of zeros (ring variant)
     int M, N, ldy, C, T, ldw;
     int Hin, Win, istr, OA, OB;
-    FastDiv div_ab, div_b, div_c;
+    FastDiv div_ab, div_b;
     int m_per_split;
-    int Kc;  // few-channel mode: number of valid reduction columns (taps * C); C then means the padded column count
+    int cp, tw;  // packed-row mode (few input channels): elements per pixel and per kernel row; C = T * tw columns
     int tap_dh[GG_MAX_TAPS];
     int tap_dw[GG_MAX_TAPS];
     int tap_woff[GG_MAX_TAPS];
@@ -707,8 +698,8 @@ __device__ __forceinline__ bf16x8 lds_read_tr8(const bf16* base_lo, const bf16* 
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// SMALLC: the "channel" axis of the X operand is the flattened (tap, c) index of a few-channel convolution
-// (the stem); each element is gathered individually, see gather_gemm_kernel.
+// SMALLC: packed rows of a few-channel convolution (the stem), see gather_gemm_kernel: the "channel" axis of
+// the X operand is (kernel row, position in the row) and every chunk is one contiguous 16-byte load.
 template <int BT, bool SMALLC>  // BT x BT output tile (n x c), BT in {64, 128}
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     constexpr int KM = 64;             // pixels per K-step
@@ -751,16 +742,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     bf16x8 ry[NP], rx[NP];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    int e_dh[8], e_dw[8], e_c[8];  // few-channel mode: decoded (tap offset, channel) of this thread's 8 columns
+    int s_kh = 0, s_piece = 0;  // packed rows: kernel row and 16-byte piece of this thread's 8 columns
     if (SMALLC) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = c0 + chunk * 8 + e;
-            const int t = min(static_cast<int>(fastdiv(k, p.div_c)), p.T - 1);
-            e_c[e] = k - t * (p.Kc / p.T);
-            e_dh[e] = k < p.Kc ? p.tap_dh[t] : -(1 << 24);
-            e_dw[e] = p.tap_dw[t];
-        }
+        const int cc = (c0 >> 3) + chunk, cpr = p.tw >> 3;
+        s_kh = min(cc / cpr, p.T - 1);
+        s_piece = cc % cpr;
     }
     auto load_step = [&](int mbase) {
 #pragma unroll
@@ -770,21 +756,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             ry[i] = (mok && y_ok) ? *reinterpret_cast<const bf16x8*>(p.dY + static_cast<size_t>(m) * p.ldy + n0 + chunk * 8)
                                   : zero8;
             if (SMALLC) {
-                const int cr = p.Kc / p.T;  // real channel count
-                if (mok) {
+                if (mok && x_ok) {
                     const uint32_t img = fastdiv(m, p.div_ab);
                     const uint32_t rem = m - img * (p.OA * p.OB);
                     const uint32_t a = fastdiv(rem, p.div_b);
                     const uint32_t b = rem - a * p.OB;
-                    const int h0 = static_cast<int>(a) * p.istr, w0 = static_cast<int>(b) * p.istr;
-                    const uint32_t pix = img * (p.Hin * p.Win);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int ih = h0 + e_dh[e], iw = w0 + e_dw[e];
-                        const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
-                                        static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
-                        rx[i][e] = ok ? p.X[(pix + ih * p.Win + iw) * cr + e_c[e]] : static_cast<bf16>(0.f);
-                    }
+                    const uint32_t off = ((img * p.Hin + a * p.istr + s_kh) * p.Win + b * p.istr) * p.cp + s_piece * 8;
+                    rx[i] = *reinterpret_cast<const bf16x8*>(p.X + off);
                 } else {
                     rx[i] = zero8;
                 }
@@ -1073,13 +1051,15 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.Hin = Hin; a.Win = Win; a.istr = istr; a.OA = OA; a.OB = OB;
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
     a.div_b = make_fastdiv(OB);
-    a.Kc = 0;
-    a.div_c = make_fastdiv(1);
+    a.cp = 0;
+    a.tw = 0;
     if (smallc) {
-        // C = real channel count on entry; the kernel sees the flattened, padded (tap, c) axis as its channel axis
-        a.Kc = T * C;
-        a.div_c = make_fastdiv(C);
-        a.C = (T * C + 7) / 8 * 8;
+        // packed rows: `smallc` is the row width tw, C the elements per pixel on entry, T the number of kernel rows;
+        // the kernel sees (kernel row, position in row) as its channel axis
+        if ((smallc != 32 && smallc != 64) || (C != 4 && C != 8) || tile >= 10) return -1;
+        a.cp = C;
+        a.tw = smallc;
+        a.C = T * smallc;
         if (ldw < a.C) return -1;
     }
     int mps = pdt_cdiv(M, splits);

@@ -33,46 +33,42 @@ PDT_API int pdt_nchw_to_nhwc_bf16(const void* x, void* out, int NB, int C, int H
     return pdt_launch_status();
 }
 
-// out[m][k], m = (n, ho, wo), k = (r*S + s)*C + c for k < R*S*C, zero for the padding columns
-__global__ __launch_bounds__(256) void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int NB, int H, int W,
-                                                    int C, int R, int S, int stride, int pad, int Ho, int Wo, int Kpad) {
-    const int kvec = Kpad >> 3;
-    const long long nvec = static_cast<long long>(NB) * Ho * Wo * kvec;
-    const int K = R * S * C;
-    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
-        const int kc = static_cast<int>(v % kvec);
-        long long m = v / kvec;
-        const int wo = static_cast<int>(m % Wo);
-        m /= Wo;
-        const int ho = static_cast<int>(m % Ho);
-        const int n = static_cast<int>(m / Ho);
-        bf16x8 o;
+// Few-channel images for the packed-row convolution: out[n][hp][wp][0..CP) = x[n][hp - pad][wp - pad][0..C)
+// inside the image, zero on the border and in the padding channels (CP in {4, 8}; one 8- or 16-byte store
+// per pixel).  The convolution then reads whole kernel rows as contiguous, bounds-check-free vectors.
+template <int CP>
+__global__ __launch_bounds__(256) void pad_pixels_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int NB, int H, int W,
+                                                        int C, int Hp, int Wp, int pad) {
+    typedef __attribute__((ext_vector_type(CP))) __bf16 vec_t;
+    const long long npix = static_cast<long long>(NB) * Hp * Wp;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < npix; v += gridDim.x * 256ll) {
+        const int wp = static_cast<int>(v % Wp);
+        long long t = v / Wp;
+        const int hp = static_cast<int>(t % Hp);
+        const int n = static_cast<int>(t / Hp);
+        const int ih = hp - pad, iw = wp - pad;
+        vec_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = kc * 8 + e;
-            float val = 0.f;
-            if (k < K) {
-                const int c = k % C, rs = k / C;
-                const int s = rs % S, r = rs / S;
-                const int ih = ho * stride - pad + r, iw = wo * stride - pad + s;
-                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                    val = bf16_to_f32(x[((static_cast<size_t>(n) * H + ih) * W + iw) * C + c]);
-            }
-            o[e] = f32_to_bf16(val);
+        for (int e = 0; e < CP; ++e) o[e] = f32_to_bf16(0.f);
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+            const bf16* src = x + ((static_cast<size_t>(n) * H + ih) * W + iw) * C;
+#pragma unroll
+            for (int e = 0; e < CP; ++e)
+                if (e < C) o[e] = src[e];
         }
-        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+        *reinterpret_cast<vec_t*>(out + v * CP) = o;
     }
 }
 
-PDT_API int pdt_im2col(const void* x, void* out, int NB, int H, int W, int C, int R, int S, int stride, int pad, int Kpad,
-                       void* stream) {
-    if (NB <= 0 || C <= 0 || Kpad < R * S * C || (Kpad % 8) != 0) return -1;
-    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-    const long long nvec = static_cast<long long>(NB) * Ho * Wo * (Kpad / 8);
-    long long g = (nvec + 255) / 256;
-    g = g > 16384 ? 16384 : g;
-    hipLaunchKernelGGL(im2col_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16*>(x),
-                       static_cast<bf16*>(out), NB, H, W, C, R, S, stride, pad, Ho, Wo, Kpad);
+PDT_API int pdt_pad_pixels(const void* x, void* out, int NB, int H, int W, int C, int CP, int Hp, int Wp, int pad, void* stream) {
+    if (NB <= 0 || C <= 0 || C > CP || (CP != 4 && CP != 8) || Hp <= 0 || Wp <= 0 || pad < 0) return -1;
+    long long g = (static_cast<long long>(NB) * Hp * Wp + 255) / 256;
+    g = g > 32768 ? 32768 : g;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (CP == 4)
+        hipLaunchKernelGGL(pad_pixels_kernel<4>, dim3(g), dim3(256), 0, s, static_cast<const bf16*>(x), static_cast<bf16*>(out), NB, H, W, C, Hp, Wp, pad);
+    else
+        hipLaunchKernelGGL(pad_pixels_kernel<8>, dim3(g), dim3(256), 0, s, static_cast<const bf16*>(x), static_cast<bf16*>(out), NB, H, W, C, Hp, Wp, pad);
     return pdt_launch_status();
 }
 

@@ -56,7 +56,7 @@ _avgpool_bwd = _sig("pdt_avgpool_bwd", [_vp, _vp, _i, _i, _i, _vp])
 _ce_fwd = _sig("pdt_softmax_ce_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp])
 _ce_bwd = _sig("pdt_softmax_ce_bwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _vp])
 _nchw_to_nhwc = _sig("pdt_nchw_to_nhwc_bf16", [_vp, _vp, _i, _i, _i, _i, _i, _vp])
-_im2col = _sig("pdt_im2col", [_vp, _vp] + [_i] * 9 + [_vp])
+_pad_pixels = _sig("pdt_pad_pixels", [_vp, _vp] + [_i] * 8 + [_vp])
 _cast_pad = _sig("pdt_cast_pad_f32_bf16", [_vp, _vp, _ll, _i, _i, _vp])
 _transpose_w = _sig("pdt_transpose_w", [_vp, _vp, _i, _i, _i, _vp])
 _mt_step = _sig("pdt_multi_tensor_step", [_vp, _vp, _i, _i] + [_f] * 9 + [_i, _vp])
@@ -372,7 +372,7 @@ def _pick_tile(m: int, n: int) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None, smallc=False, addend_bits=None) -> None:
+                        oph, opw, addend=None, smallc=0, addend_bits=None) -> None:
     dh = _int_array([t[0] for t in taps])
     dw = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
@@ -409,7 +409,7 @@ def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int]
     return max(1, min(max(min(want, cap), floor), M // 256))
 
 
-def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=False) -> None:
+def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=0) -> None:
     if WGRAD_RING and not smallc and N >= 128 and C >= 128:
         # LDS-DMA ring kernel, one workgroup of 8 waves per CU; the 256-wide side goes to the larger dimension
         if WGRAD_RING >= 10:
@@ -421,7 +421,7 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
     else:
         tile = 0 if (N > 64 and C > 64 and not smallc) else 1
         bt = 128 if tile == 0 else 64
-        splits = _wgrad_splits(M, N, C * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
+        splits = _wgrad_splits(M, N, smallc * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
     dh = _int_array([t[0] for t in taps])
     dwi = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
@@ -447,6 +447,26 @@ class ResidualLink:
         self.grad = None   # gradient tensor to add (the block output's gradient)
         self.bits = None   # optional ReLU mask bits gating it (then grad * mask is what gets added)
         self.armed = False  # set in forward by the convolution that will consume the gradient
+
+
+_PACKED_W: Dict[int, tuple] = {}
+
+
+def _packed_rows_weight(weight: torch.Tensor, cp: int, tw: int, kpad: int) -> torch.Tensor:
+    """bf16 [N][kpad] weights of a few-channel convolution in packed-row order: column kh*tw + kw*cp + c, zeros
+    at padding channels, beyond the kernel width and beyond the last kernel row.  Rebuilt once per optimizer step."""
+    key = id(weight)
+    hit = _PACKED_W.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (SHADOWS.epoch, weight._version, weight.data_ptr(), cp, tw, kpad):
+        return hit[2]
+    n, c, r, s = weight.shape
+    w = weight.detach().permute(0, 2, 3, 1)  # [n][r][s][c]
+    buf = torch.zeros((n, kpad), dtype=torch.bfloat16, device=weight.device)
+    buf[:, : r * tw].view(n, r, tw // cp, cp)[:, :, :s, :c].copy_(w)
+    import weakref
+
+    _PACKED_W[key] = (weakref.ref(weight), (SHADOWS.epoch, weight._version, weight.data_ptr(), cp, tw, kpad), buf)
+    return buf
 
 
 class _ConvStats(torch.autograd.Function):
@@ -480,16 +500,23 @@ class _ConvStats(torch.autograd.Function):
             _launch_gather_gemm(x, wb, y, stats, None, M, n, r * s * c, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0)
             ctx.save_for_backward(x, weight)
         else:
-            # few input channels (the stem): the kernel decodes (tap, channel) per element, no patch matrix
-            if r * s > 49:
-                raise ValueError("few-channel convolutions support at most 49 taps")
-            kpad = _round_up(r * s * c, 64)
-            wb = SHADOWS.fwd(weight, pad_cols_to=64)
-            taps = [(i - padding, j - padding, 0) for i in range(r) for j in range(s)]
-            _launch_gather_gemm(x, wb, y, stats, None, M, n, kpad, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0,
-                                smallc=True)
-            ctx.save_for_backward(x, weight)
-            ctx.col = kpad
+            # few input channels (the stem), packed rows: the image is copied once into a zero-bordered buffer with
+            # CP elements per pixel; a kernel row of an output pixel is then `tw` contiguous elements and the
+            # convolution is a GEMM with K = r * tw whose operand chunks are plain 16-byte loads (no patch matrix)
+            cp = 4 if c <= 4 else 8
+            tw = _round_up(s * cp, 32)
+            if c > 8 or tw > 64 or r > 49:
+                raise NotImplementedError("few-channel convolution: needs Cin <= 8 and a kernel row of at most 64 elements")
+            hp, wp = (ho - 1) * stride + r, (wo - 1) * stride + tw // cp
+            xp = torch.empty((nb, hp, wp, cp), dtype=torch.bfloat16, device=x.device)
+            _check_size(xp)
+            _check(_pad_pixels(x.data_ptr(), xp.data_ptr(), nb, h, w_, c, cp, hp, wp, padding, _stream()), "pad_pixels")
+            kpad = _round_up(r * tw, 64)
+            wb = _packed_rows_weight(weight, cp, tw, kpad)
+            _launch_gather_gemm(xp, wb, y, stats, None, M, n, kpad, n, cp, [(0, 0, 0)] * r, hp, wp, stride, ho, wo, ho, wo,
+                                1, 0, 0, smallc=tw)
+            ctx.save_for_backward(xp, weight)
+            ctx.col = (kpad, cp, tw, hp, wp)
         if want_stats:
             ctx.mark_non_differentiable(stats)
         return y, stats
@@ -512,11 +539,15 @@ class _ConvStats(torch.autograd.Function):
                 if sink is None:
                     dw = dwp.permute(0, 3, 1, 2)
             else:
-                kpad = ctx.col
+                kpad, cp, tw, hp, wp = ctx.col
                 dwp = torch.zeros((n, kpad), dtype=torch.float32, device=dy.device)
-                taps = [(i - padding, j - padding, 0) for i in range(r) for j in range(s)]
-                _launch_wgrad(dy, saved, dwp, M, n, n, c, taps, kpad, h, w_, stride, ho, wo, smallc=True)
-                dw = dwp[:, : r * s * c].reshape(n, r, s, c).permute(0, 3, 1, 2)
+                _launch_wgrad(dy, saved, dwp, M, n, n, cp, [(0, 0, 0)] * r, kpad, hp, wp, stride, ho, wo, smallc=tw)
+                real = dwp[:, : r * tw].view(n, r, tw // cp, cp)[:, :, :s, :c]  # [n][r][s][c]: drop the padding positions
+                sink = _grad_sink(weight, (n, r, s, c))
+                if sink is not None:
+                    sink.add_(real)
+                else:
+                    dw = real.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[0]:
             if ctx.col is not None:
                 raise NotImplementedError("data gradient of a convolution with Cin % 64 != 0")
@@ -981,10 +1012,16 @@ def multi_tensor_step(plan: MultiTensorPlan, group, hyper_block: Optional[torch.
                      bc1, bc2s, mom, gs, first, _stream()),
             "multi_tensor_step",
         )
+    note_parameters_updated(plan)
+    ARENA.reset()
+
+
+def note_parameters_updated(plan: MultiTensorPlan) -> None:
+    """Host-side bookkeeping after the update kernel of ``plan`` ran (or was replayed from a hipGraph): every
+    derived weight copy is stale except the bf16 copies the kernel itself rewrote."""
     SHADOWS.epoch += 1
     for p in plan.shadow_params:
         SHADOWS.mark_refreshed(p)
-    ARENA.reset()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -94,6 +94,15 @@ class FusedOptimizer(Optimizer):
                 block = self._hyper_blocks[gi] = hip.new_hyper_block(params[0].device)
             hip.upload_hyper(block, group)
 
+    def notify_replayed(self) -> None:
+        """Capturable mode: a hipGraph that contains this optimizer's update kernels has just been replayed.
+        The replay ran no host code, so redo the host-side bookkeeping of a step (which derived weight copies
+        are fresh) for code that runs eagerly afterwards."""
+        from ..ops import hip
+
+        for plan in self._plans.values():
+            hip.note_parameters_updated(plan)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -65,5 +65,6 @@ class GraphedStep:
                 dst.copy_(src, non_blocking=True)
         self.optimizer.advance()
         self.graph.replay()
+        self.optimizer.notify_replayed()
         self.replays += 1
         return self.static_loss

@@ -347,11 +347,56 @@ def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypa
     assert _rel_err(wa, blk.conv1.weight.grad) < 1e-6
 
 
+def test_capturable_optimizer_matches_plain_steps():
+    """Adam with device-resident hyper-parameters - eagerly and replayed from a hipGraph - takes the same steps
+    as the plain launch: the step count, bias corrections and a changed learning rate all reach the kernel."""
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    dev = _dev()
+    torch.manual_seed(9)
+    shapes = [(64, 3, 7, 7), (256,), (1000, 512), (37,)]
+    grads = [[torch.randn(*sh, device=dev) for sh in shapes] for _ in range(6)]
+
+    def run(mode: str):
+        torch.manual_seed(10)
+        params = [nn.Parameter(torch.randn(*sh, device=dev)) for sh in shapes]
+        opt = FusedOptimizer(params, mode="adam", lr=1e-2, weight_decay=1e-2)
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        if mode != "plain":
+            opt.set_capturable(True)
+        graph = None
+        for i, gs in enumerate(grads):
+            if i == 3:
+                opt.param_groups[0]["lr"] = 3e-3  # schedules change hyper-parameters between steps
+            for p, g in zip(params, gs):
+                p.grad.copy_(g)
+            if mode == "graph" and i >= 2:
+                if graph is None:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        opt.step()
+                opt.advance()
+                graph.replay()
+                opt.notify_replayed()
+            else:
+                opt.step()
+        assert opt.param_groups[0]["step"] == len(grads)
+        return [p.detach().clone() for p in params]
+
+    ref = run("plain")
+    for mode in ("capturable", "graph"):
+        got = run(mode)
+        for a, b in zip(got, ref):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), mode
+
+
 def test_recorded_step_matches_eager_training():
-    """A hipGraph replay of the whole step (zero-grad, forward, backward, Adam update with device-resident
-    hyper-parameters) does what the eager step does.  The first replayed step starts from bit-identical
-    state and must agree tightly; later steps only loosely (fp32 atomics make summation order vary, and
-    a batch-16 BatchNorm network amplifies last-bit differences quickly)."""
+    """A hipGraph replay of the whole step (zero-grad, forward, backward, optimizer update) does what the eager
+    step does.  SGD keeps the comparison meaningful: fp32 atomics make the summation order, hence the last bits
+    of the gradients, vary between runs, and Adam would turn last-bit noise on near-zero gradient elements
+    into full-size steps of either sign."""
     from pytorch_distributed_training_amd import ops
     from pytorch_distributed_training_amd.models import build_model
     from pytorch_distributed_training_amd.optim import FusedOptimizer
@@ -365,7 +410,7 @@ def test_recorded_step_matches_eager_training():
     def run(graphed: bool):
         torch.manual_seed(6)
         model = ops.prepare_module(build_model("resnet18", 10, 32).to(dev).to(memory_format=torch.channels_last))
-        opt = FusedOptimizer(model.parameters(), mode="adam", lr=1e-3, weight_decay=1e-3)
+        opt = FusedOptimizer(model.parameters(), mode="sgd", lr=0.002, momentum=0.9, weight_decay=1e-4)  # a stable trajectory
         opt.zero_grad()
 
         def body(x, y):
@@ -375,18 +420,31 @@ def test_recorded_step_matches_eager_training():
             opt.zero_grad()
             return loss.detach()
 
-        losses, snap = [], None
+        losses = []
         step = None
         for i, (x, y) in enumerate(zip(xs, ys)):
             if graphed and i == 2:
                 step = GraphedStep(body, opt, (x, y))
             losses.append(float(step(x, y) if step is not None else body(x, y)))
-            if i == 2:
-                snap = [p.detach().clone() for p in model.parameters()]
         assert opt.param_groups[0]["step"] == len(xs)
         if graphed:
             assert step.replays == len(xs) - 2
-        return losses, snap
+            # code that runs eagerly after replays (evaluation, a last smaller batch) must see current weights in
+            # every derived copy: the bf16 copies the recorded optimizer kernel rewrites, and the lazily rebuilt
+            # ones (packed stem rows, transposed data-gradient weights) whose host-side freshness marks a replay
+            # does not touch by itself
+            from pytorch_distributed_training_amd.ops import hip as h
+
+            w = model.conv1.weight
+            n, c, r, s_ = w.shape
+            packed = h._packed_rows_weight(w, 4, 32, 256)
+            assert torch.equal(packed[:, : r * 32].view(n, r, 8, 4)[:, :, :s_, :c], w.detach().permute(0, 2, 3, 1).to(torch.bfloat16))
+            w2 = model.layer1[0].conv1.weight
+            phys = w2.detach().permute(0, 2, 3, 1).reshape(w2.shape[0], -1).to(torch.bfloat16)
+            assert torch.equal(h.SHADOWS.fwd(w2), phys)
+            wt, npad = h.SHADOWS.dgrad(w2, 9)
+            assert torch.equal(wt.view(w2.shape[1], 9, npad), phys.view(w2.shape[0], 9, w2.shape[1]).permute(2, 1, 0))
+        return losses, [p.detach().clone() for p in model.parameters()]
 
     def rel(pa, pb):
         num = sum(float((a - b).norm() ** 2) for a, b in zip(pa, pb)) ** 0.5
@@ -395,9 +453,8 @@ def test_recorded_step_matches_eager_training():
     le, pe = run(False)
     lg, pg = run(True)
     assert all(math.isfinite(v) for v in lg)
-    assert le[:3] == pytest.approx(lg[:3], abs=1e-4)   # identical state up to and including the first replay
-    assert rel(pe, pg) < 1e-3                            # ... and the same Adam update (third step: bias corrections)
-    assert max(abs(a - b) for a, b in zip(le, lg)) < 0.3, (le, lg)
+    assert le == pytest.approx(lg, abs=2e-2), (le, lg)
+    assert rel(pe, pg) < 2e-3, rel(pe, pg)
 
 
 def test_no_kernel_reads_memory_it_did_not_write(monkeypatch):
