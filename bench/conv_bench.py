@@ -95,6 +95,7 @@ def main():
             geom = (args.batch, cin, hw, hw, cout, k, k, ho, ho, stride, pad)
             col = None
             link = None
+            link_out = None
             needs_input_grad = (False, False, False, False, False)
 
         def dgrad():

@@ -48,12 +48,14 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        link = ops.residual_link(x) if self.downsample is None else None
+        # both consumers of x hand their input gradients to one kernel: the shortcut's (block tail or projection
+        # convolution) is added inside the data-gradient kernel of conv1
+        link = ops.residual_link(x)
         y1, s1 = ops.conv2d_stats(x, self.conv1.weight, self.conv1.s, self.conv1.p, self.training, link)
         y2, s2 = ops.bn_relu_conv2d(y1, s1, self.bn1, self.conv2.weight, 1, 1)
         if self.downsample is not None:
             dconv, dbn = self.downsample[0], self.downsample[1]
-            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p, self.training)
+            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p, self.training, link_out=link)
             return ops.bn_add_relu(y2, s2, self.bn2, yd, sd, dbn)
         return ops.bn_add_relu(y2, s2, self.bn2, x, link=link)
 
@@ -72,13 +74,13 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        link = ops.residual_link(x) if self.downsample is None else None
+        link = ops.residual_link(x)  # see BasicBlock.forward
         y1, s1 = ops.conv2d_stats(x, self.conv1.weight, 1, 0, self.training, link)
         y2, s2 = ops.bn_relu_conv2d(y1, s1, self.bn1, self.conv2.weight, self.conv2.s, 1)
         y3, s3 = ops.bn_relu_conv2d(y2, s2, self.bn2, self.conv3.weight, 1, 0)
         if self.downsample is not None:
             dconv, dbn = self.downsample[0], self.downsample[1]
-            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p, self.training)
+            yd, sd = ops.conv2d_stats(x, dconv.weight, dconv.s, dconv.p, self.training, link_out=link)
             return ops.bn_add_relu(y3, s3, self.bn3, yd, sd, dbn)
         return ops.bn_add_relu(y3, s3, self.bn3, x, link=link)
 

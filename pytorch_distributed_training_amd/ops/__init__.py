@@ -23,18 +23,23 @@ def _hip():
 
 
 def residual_link(x):
-    """Token shared by the first convolution of a residual block and the block tail (both consume the block
-    input ``x``): on GPU it lets the shortcut gradient be added inside the convolution's data-gradient kernel
-    instead of in a separate pass.  ``None`` (no effect) for CPU tensors."""
+    """Token shared by the first convolution of a residual block and the other consumer of the block input
+    ``x`` (the block tail, or the projection convolution of a down-sampling block): on GPU it lets the
+    shortcut's gradient be added inside the first convolution's data-gradient kernel instead of in a separate
+    pass.  ``None`` (no effect) for CPU tensors."""
     return _hip().residual_link() if x.is_cuda else None
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None):
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None, link_out=None):
     """Convolution without bias.  Returns ``(y, stats)`` where ``stats`` carries the per-channel
     batch statistics of ``y`` gathered in the kernel epilogue (``None`` on CPU or when not wanted,
-    e.g. in inference where BatchNorm uses its running statistics)."""
+    e.g. in inference where BatchNorm uses its running statistics).
+
+    ``link`` / ``link_out`` (see :func:`residual_link`): with ``link`` this convolution's data-gradient kernel
+    adds whatever gradient the link carries; with ``link_out`` this convolution hands its input gradient to the
+    link instead of returning it to autograd."""
     if x.is_cuda:
-        return _hip().conv2d_stats(x, weight, stride, padding, want_stats, link)
+        return _hip().conv2d_stats(x, weight, stride, padding, want_stats, link, link_out)
     return _ref.conv2d_stats(x, weight, stride, padding)
 
 

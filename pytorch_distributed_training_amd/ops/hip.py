@@ -441,12 +441,13 @@ class ResidualLink:
     kernel of the block's first convolution, which adds it in its epilogue.  Both consume the same block
     input ``x``; without the link autograd would materialise both gradients and add them in a separate pass."""
 
-    __slots__ = ("grad", "bits", "armed")
+    __slots__ = ("grad", "bits", "armed", "consumed")
 
     def __init__(self):
-        self.grad = None   # gradient tensor to add (the block output's gradient)
+        self.grad = None   # gradient tensor to add (the block output's gradient, or the projection's input gradient)
         self.bits = None   # optional ReLU mask bits gating it (then grad * mask is what gets added)
         self.armed = False  # set in forward by the convolution that will consume the gradient
+        self.consumed = False  # set in backward once that convolution has run: later producers must not use the link
 
 
 _PACKED_W: Dict[int, tuple] = {}
@@ -473,7 +474,8 @@ class _ConvStats(torch.autograd.Function):
     """y = conv2d(x, w) (no bias) and per-channel statistic accumulators of y."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, padding: int, want_stats: bool, link: Optional[ResidualLink] = None):
+    def forward(ctx, x, weight, stride: int, padding: int, want_stats: bool, link: Optional[ResidualLink] = None,
+                link_out: Optional[ResidualLink] = None):
         x = _as_nhwc(x)
         nb, c, h, w_ = x.shape
         n, c2, r, s = weight.shape
@@ -490,6 +492,8 @@ class _ConvStats(torch.autograd.Function):
         ctx.geom = (nb, c, h, w_, n, r, s, ho, wo, stride, padding)
         ctx.col = None
         ctx.link = None
+        # producer side: usable only if the consuming convolution (called earlier in forward) armed the link
+        ctx.link_out = link_out if (link_out is not None and link_out.armed and ctx.needs_input_grad[0]) else None
         ctx.set_materialize_grads(False)  # the statistics output never carries a gradient: do not zero-fill one
         if link is not None and c % 64 == 0 and stride == 1 and ctx.needs_input_grad[0]:
             link.armed = True
@@ -525,8 +529,10 @@ class _ConvStats(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         saved, weight = ctx.saved_tensors
         nb, c, h, w_, n, r, s, ho, wo, stride, padding = ctx.geom
+        if ctx.link is not None:
+            ctx.link.consumed = True
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dy = _as_nhwc(dy)
         M = nb * ho * wo
         dx = dw = None
@@ -581,11 +587,15 @@ class _ConvStats(torch.autograd.Function):
                                         oa, ob, h, w_, stride, ph, pw, addend, addend_bits=addend_bits)
         elif ctx.link is not None and ctx.link.grad is not None:
             raise RuntimeError("residual link armed but the convolution input needs no gradient")
-        return dx, dw, None, None, None, None
+        if dx is not None and ctx.link_out is not None and not ctx.link_out.consumed and ctx.link_out.grad is None:
+            # the consumer's data-gradient kernel (it runs later: it was created earlier in forward) adds this
+            ctx.link_out.grad, ctx.link_out.bits = dx, None
+            dx = None
+        return dx, dw, None, None, None, None, None
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None):
-    return _ConvStats.apply(x, weight, stride, padding, want_stats, link)
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None, link_out=None):
+    return _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out)
 
 
 def residual_link():

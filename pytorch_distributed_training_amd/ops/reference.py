@@ -32,7 +32,7 @@ def batch_norm(y: torch.Tensor, bn: nn.BatchNorm2d) -> torch.Tensor:
     )
 
 
-def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None):
+def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None, link_out=None):
     return F.conv2d(x, weight, None, stride, padding), None
 
 

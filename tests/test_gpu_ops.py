@@ -313,16 +313,23 @@ def test_resnet18_matches_reference_model_and_learns():
     assert losses[-1] < 0.6 * losses[0]
 
 
-def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypatch):
-    """The shortcut gradient added in the dgrad epilogue equals the one autograd would add in a separate pass."""
+@pytest.mark.parametrize("projected", [False, True])
+def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypatch, projected):
+    """The shortcut gradient added in the dgrad epilogue (from the block tail of an identity block, from the
+    projection convolution of a down-sampling block) equals the one autograd would add in a separate pass."""
     from pytorch_distributed_training_amd import ops
-    from pytorch_distributed_training_amd.models.resnet import Bottleneck
+    from pytorch_distributed_training_amd.models.resnet import Bottleneck, Conv2d
 
     torch.manual_seed(7)
     dev = _dev()
-    blk = Bottleneck(256, 64).to(dev).to(memory_format=torch.channels_last)
+    if projected:
+        ds = nn.Sequential(Conv2d(256, 512, 1, 2, 0), nn.BatchNorm2d(512))
+        blk = Bottleneck(256, 128, 2, ds).to(dev).to(memory_format=torch.channels_last)
+        g = hip.to_device_layout(torch.randn(4, 512, 7, 7, device=dev))
+    else:
+        blk = Bottleneck(256, 64).to(dev).to(memory_format=torch.channels_last)
+        g = hip.to_device_layout(torch.randn(4, 256, 14, 14, device=dev))
     x0 = hip.to_device_layout(torch.randn(4, 256, 14, 14, device=dev))
-    g = hip.to_device_layout(torch.randn(4, 256, 14, 14, device=dev))
     links = []
     real_link = ops.residual_link
 
@@ -334,7 +341,7 @@ def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypa
     monkeypatch.setattr(ops, "residual_link", spy)
     xa = x0.clone().requires_grad_(True)
     blk(xa).backward(g)
-    assert len(links) == 1 and links[0].armed and links[0].grad is None  # produced and consumed
+    assert len(links) == 1 and links[0].armed and links[0].consumed and links[0].grad is None  # produced and consumed
     wa = blk.conv1.weight.grad.clone()
     blk.zero_grad(set_to_none=True)
     monkeypatch.setattr(ops, "residual_link", lambda x: None)
