@@ -29,7 +29,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-size", type=int, default=1024, help="per-GPU batch (sized for 288 GB of HBM)")
+    ap.add_argument("--batch-size", type=int, default=2048, help="per-GPU batch (sized for 288 GB of HBM: ~80 GiB at 2048)")
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=1024)
@@ -153,7 +153,13 @@ def main():
                 "bucket_mb": args.bucket_mb,
             },
             "final_loss": round(final_loss, 4),
+            "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1) if on_gpu else None,
         }
+        # the reference publishes no number (vs_baseline stays null); the same model on stock PyTorch-ROCm
+        # (bench/stock_baseline.py, 1x MI355X) is the self-measured yardstick
+        stock = {"resnet50": 5959.0, "vit_b_16": 3494.3, "gpt2_medium": 180905.5}.get(args.model)
+        if stock and on_gpu:
+            out["vs_stock_pytorch_rocm_per_gpu"] = round(value / (stock * env.world_size), 3)
         print(json.dumps(out), flush=True)
     if env.distributed:
         model.reducer.close()
