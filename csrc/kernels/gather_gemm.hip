@@ -680,7 +680,7 @@ struct WgradArgs {
     const bf16* zeros;  // >= 16 bytes of zeros (ring variant)
     int M, N, ldy, C, T, ldw;
     int Hin, Win, istr, OA, OB;
-    FastDiv div_ab, div_b;
+    FastDiv div_ab, div_b, div_c;
     int m_per_split;
     int cp, tw;  // packed-row mode (few input channels): elements per pixel and per kernel row; C = T * tw columns
     int tap_dh[GG_MAX_TAPS];
@@ -859,7 +859,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // row & 7, applied to the per-lane source address and again by the transposed fragment reads: the 8
 // consecutive rows a 32-lane half of `ds_read_b64_tr_b16` touches then fall on 8 distinct bank groups.
 // ------------------------------------------------------------------------------------------------
-template <int BN, int BC, int WN, int WC, int NS>
+// MODE 0: the column axis of the weight tile is the flattened (tap, channel) index, so a tile may span several
+//         taps (a 64-channel 3x3 layer puts four taps into one 256-wide tile and reads dY once for them).
+// MODE 1: packed rows of a few-channel convolution (see gather_gemm_kernel): column = (kernel row, position).
+template <int BN, int BC, int WN, int WC, int NS, int MODE>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
     constexpr int KM = 64;                       // pixels per K-step
     constexpr int NW = WN * WC;
@@ -872,30 +875,54 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     constexpr int STAGE = KM * (BN + BC);        // elements: [Y tile | X tile]
     static_assert((KM / YR) % NW == 0 && (KM / XR) % NW == 0, "whole DMA pieces per wave");
     static_assert(NS >= 3 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
-    static_assert(YR <= 8 && XR <= 8 && BN >= 128 && BC >= 128, "rows of at least 256 bytes");
+    static_assert(YR <= 8 && XR <= 8 && BN >= 64 && BC >= 64, "rows of at least 128 bytes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    const int tiles_c = (p.C + BC - 1) / BC;
+    const int KC = p.T * p.C;  // columns of the weight gradient (MODE 1: C is the row width tw)
+    const int tiles_c = (KC + BC - 1) / BC;
     // workgroups of one pixel range share their operand rows: consecutive logical ids, one XCD (see wgrad_kernel)
     const int lin = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-    int bid = lin % gridDim.x;
+    const int bid = lin % gridDim.x;
     const int split = lin / gridDim.x;
-    const int tap = bid % p.T;
-    bid /= p.T;
     const int tc = bid % tiles_c, tn = bid / tiles_c;
     const int n0 = tn * BN, c0 = tc * BC;
     const int ms = split * p.m_per_split;
     const int me = min(p.M, ms + p.m_per_split);
-    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
     const int nsteps = (me - ms + KM - 1) / KM;
 
-    // loader: lane -> (row inside a piece, physical chunk); the logical chunk it fetches undoes the swizzle.
-    // Pieces start at multiples of YR / XR rows, so row & 7 is known per piece.
+    // 32-byte units of a row are XOR-ed with a function of the row so that the 8 consecutive rows one half of a
+    // transposed read touches fall on 8 distinct bank groups: row & 7 for rows of 256 bytes or more (every row
+    // starts on bank 0), (row >> 1) & 3 for 128-byte rows (two rows per 256-byte bank line).
+    auto swz_y = [](int row) { return BN == 64 ? ((row >> 1) & 3) : (row & 7); };
+    auto swz_x = [](int row) { return BC == 64 ? ((row >> 1) & 3) : (row & 7); };
+
+    // loader: lane -> (row inside a piece, physical chunk); the logical chunk it fetches undoes the swizzle
     const int y_lr = lane / YCH, y_pc = lane % YCH;
     const int x_lr = lane / XCH, x_pc = lane % XCH;
+    int x_dh[XI], x_dw[XI], x_cc[XI];  // per piece: tap offset and channel (MODE 0) / kernel row, -, position (MODE 1)
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave * XI + i) * XR + x_lr;
+        const int j = c0 + ((((x_pc >> 1) ^ swz_x(row)) << 1) | (x_pc & 1)) * 8;  // first of this lane's 8 columns
+        if (j >= KC) {
+            x_dh[i] = -(1 << 24);
+            x_dw[i] = 0;
+            x_cc[i] = 0;
+        } else if (MODE == 1) {
+            const int cpr = p.tw >> 3, cc = j >> 3;
+            x_dh[i] = cc / cpr;
+            x_dw[i] = 0;
+            x_cc[i] = (cc % cpr) * 8;
+        } else {
+            const int tap = fastdiv(j, p.div_c);
+            x_dh[i] = p.tap_dh[tap];
+            x_dw[i] = p.tap_dw[tap];
+            x_cc[i] = j - tap * p.C;
+        }
+    }
     int ld_issued = 0, ld_slot = 0;
     auto issue_stage = [&]() {
         const int mbase = ms + ld_issued * KM;
@@ -904,7 +931,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
 #pragma unroll
         for (int i = 0; i < YI; ++i) {
             const int row = (wave * YI + i) * YR + y_lr;
-            const int c = ((((y_pc >> 1) ^ (row & 7)) << 1) | (y_pc & 1)) * 8;
+            const int c = ((((y_pc >> 1) ^ swz_y(row)) << 1) | (y_pc & 1)) * 8;
             const int m = mbase + row;
             const bool ok = m < me && n0 + c < p.N;
             const bf16* src = ok ? p.dY + static_cast<size_t>(m) * p.ldy + n0 + c : p.zeros;
@@ -913,19 +940,22 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int row = (wave * XI + i) * XR + x_lr;
-            const int c = ((((x_pc >> 1) ^ (row & 7)) << 1) | (x_pc & 1)) * 8;
             const int m = mbase + row;
-            bool ok = m < me && c0 + c < p.C;
+            bool ok = m < me && x_dh[i] > -(1 << 23);
             uint32_t off = 0;
             if (ok) {
                 const uint32_t img = fastdiv(m, p.div_ab);
                 const uint32_t rem = m - img * (p.OA * p.OB);
                 const uint32_t a = fastdiv(rem, p.div_b);
                 const uint32_t b = rem - a * p.OB;
-                const int ih = static_cast<int>(a) * p.istr + dh, iw = static_cast<int>(b) * p.istr + dw;
-                ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
-                     static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
-                off = (img * (p.Hin * p.Win) + ih * p.Win + iw) * p.C + c0 + c;
+                const int ih = static_cast<int>(a) * p.istr + x_dh[i], iw = static_cast<int>(b) * p.istr + x_dw[i];
+                if (MODE == 1) {
+                    off = ((img * p.Hin + ih) * p.Win + iw) * p.cp + x_cc[i];
+                } else {
+                    ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
+                         static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
+                    off = (img * (p.Hin * p.Win) + ih * p.Win + iw) * p.C + x_cc[i];
+                }
             }
             const bf16* src = ok ? p.X + off : p.zeros;
             __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sX + (wave * XI + i) * XR * BC), 16, 0, 0);
@@ -953,19 +983,19 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
         s16x4 ylo[2][FN], yhi[2][FN], xlo[2][FC], xhi[2][FC];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int krow = kk * 32 + 4 * g + q;  // krow and krow + 16 have the same row & 7
-            const int sw = krow & 7;
+            const int krow = kk * 32 + 4 * g + q;  // krow and krow + 16 swizzle alike
+            const int swy = swz_y(krow), swx = swz_x(krow);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const int u = (wr * TN + i * 16) >> 4;
-                const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ sw) << 4) + 4 * pp) * 2u;
+                const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ swy) << 4) + 4 * pp) * 2u;
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[kk][i]) : "v"(a) : "memory");
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[kk][i]) : "v"(a), "n"(16 * BN * 2) : "memory");
             }
 #pragma unroll
             for (int j = 0; j < FC; ++j) {
                 const int u = (wc * TC + j * 16) >> 4;
-                const uint32_t a = xb + static_cast<uint32_t>(krow * BC + ((u ^ sw) << 4) + 4 * pp) * 2u;
+                const uint32_t a = xb + static_cast<uint32_t>(krow * BC + ((u ^ swx) << 4) + 4 * pp) * 2u;
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kk][j]) : "v"(a) : "memory");
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[kk][j]) : "v"(a), "n"(16 * BC * 2) : "memory");
             }
@@ -1000,36 +1030,41 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
 
-    // D[i = n][j = c]: lane holds rows (lane>>4)*4 + e, column lane&15
-    const int woff = p.tap_woff[tap];
+    // D[i = n][j = column]: lane holds rows (lane>>4)*4 + e, column lane&15
 #pragma unroll
-    for (int i = 0; i < FN; ++i)
+    for (int j = 0; j < FC; ++j) {
+        const int col = c0 + wc * TC + j * 16 + (lane & 15);
+        if (col >= KC) continue;
+        int wcol = col;
+        if (MODE == 0) {
+            const int tap = fastdiv(col, p.div_c);
+            wcol = p.tap_woff[tap] + col - tap * p.C;
+        }
 #pragma unroll
-        for (int j = 0; j < FC; ++j) {
-            const int c = c0 + wc * TC + j * 16 + (lane & 15);
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = n0 + wr * TN + i * 16 + (lane >> 4) * 4 + e;
-                if (n < p.N && c < p.C)
-                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(n) * p.ldw + woff + c, acc[i][j][e],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n < p.N)
+                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(n) * p.ldw + wcol, acc[i][j][e], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
+    }
 }
 
-template <int BN, int BC, int WN, int WC, int NS>
+template <int BN, int BC, int WN, int WC, int NS, int MODE = 0>
 static int launch_wgrad_ring(const WgradArgs& a, int gy, hipStream_t stream) {
     constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
     if (a.zeros == nullptr) return -1;
-    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS>;
+    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return static_cast<int>(e);
         configured = true;
     }
-    const int gx = pdt_cdiv(a.N, BN) * pdt_cdiv(a.C, BC) * a.T;
+    const int gx = pdt_cdiv(a.N, BN) * pdt_cdiv(a.T * a.C, BC);
     hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(WN * WC * 64), lds, stream, a);
     return pdt_launch_status();
 }
@@ -1053,14 +1088,21 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.div_b = make_fastdiv(OB);
     a.cp = 0;
     a.tw = 0;
+    a.div_c = make_fastdiv(C);
     if (smallc) {
         // packed rows: `smallc` is the row width tw, C the elements per pixel on entry, T the number of kernel rows;
         // the kernel sees (kernel row, position in row) as its channel axis
-        if ((smallc != 32 && smallc != 64) || (C != 4 && C != 8) || tile >= 10) return -1;
+        if ((smallc != 32 && smallc != 64) || (C != 4 && C != 8) || (tile >= 10 && tile != 15)) return -1;
         a.cp = C;
         a.tw = smallc;
-        a.C = T * smallc;
-        if (ldw < a.C) return -1;
+        if (ldw < T * smallc) return -1;
+        if (tile == 15) {
+            a.C = smallc;  // ring kernel: columns = T rows of tw
+        } else {
+            a.C = T * smallc;
+        }
+    } else if (tile == 15) {
+        return -1;
     }
     int mps = pdt_cdiv(M, splits);
     mps = pdt_cdiv(mps, 64) * 64;
@@ -1072,7 +1114,9 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (smallc) {
+    if (tile == 15) {
+        return launch_wgrad_ring<64, 256, 2, 4, 3, 1>(a, gy, s);
+    } else if (smallc) {
         constexpr int BT = 64;
         const int gx = pdt_cdiv(N, BT) * pdt_cdiv(a.C, BT);
         const size_t lds = 4ull * 64 * (BT + 16) * sizeof(bf16);
@@ -1093,6 +1137,10 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         return launch_wgrad_ring<256, 128, 4, 2, 3>(a, gy, s);
     } else if (tile == 12) {
         return launch_wgrad_ring<128, 256, 2, 4, 3>(a, gy, s);
+    } else if (tile == 13) {
+        return launch_wgrad_ring<64, 256, 2, 4, 3>(a, gy, s);
+    } else if (tile == 14) {
+        return launch_wgrad_ring<256, 64, 4, 2, 3>(a, gy, s);
     } else {
         return -1;
     }
