@@ -661,6 +661,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         // ring variants (persistent, LDS-DMA): need the page of zeros
         case 10: return launch_gather_gemm_ring<128, 128, 4, 2, 4>(a, s);  // 8 waves, 4 stages
         case 13: return launch_gather_gemm_ring<256, 128, 4, 2, 3>(a, s);  // 8 waves, 256-row tile
+        case 14: return launch_gather_gemm_ring<256, 64, 8, 1, 3>(a, s);   // narrow N, 32x64 per wave
         default: return -1;
     }
 }

@@ -328,7 +328,7 @@ SHADOWS = ShadowCache()
 # GEMM / convolution launch helpers
 # ------------------------------------------------------------------------------------------------
 _TILE_WIDE = int(_os.environ.get("PDT_GEMM_TILE_WIDE", "-1"))  # -1: choose per shape
-_TILE_NARROW = int(_os.environ.get("PDT_GEMM_TILE_NARROW", "1"))
+_TILE_NARROW = int(_os.environ.get("PDT_GEMM_TILE_NARROW", "-1"))  # -1: choose per shape
 _RING_MIN_TILES = int(_os.environ.get("PDT_GEMM_RING_MIN_TILES", "768"))
 
 
@@ -360,7 +360,11 @@ def _pick_tile(m: int, n: int) -> int:
     tiles through an LDS-DMA ring; it wins once every CU gets several tiles (measured per layer with
     bench/conv_bench.py), below that the tail of a partially filled last round costs more than it saves."""
     if n <= 64:
-        return _TILE_NARROW if m >= 128 else 2
+        if m < 128:
+            return 2
+        if _TILE_NARROW >= 0:
+            return _TILE_NARROW
+        return 14 if -(-m // 256) >= _RING_MIN_TILES else 1  # 256x64 ring once every CU gets several tiles
     if _TILE_WIDE >= 0:
         return _TILE_WIDE
     tiles = -(-m // 256) * -(-n // 128)
