@@ -78,12 +78,21 @@ def build_rccl(force: bool = False) -> Path:
     return out
 
 
+# Per-file code generation options.  The attention kernels post-process every MFMA result on the vector ALU
+# (softmax, dS): with accumulators in AGPRs each value costs a v_accvgpr_read/write pair, so MFMA is asked
+# to use VGPR destinations there.
+EXTRA_FLAGS = {
+    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
+
+
 def _compile_kernel(src: Path, headers: List[Path], force: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
-    if force or _newer(obj, [src] + headers):
+    if force or _newer(obj, [src] + headers + [Path(__file__)]):
         _run(
             [
                 _hipcc(), "-O3", "-std=c++17", "-fPIC", "-c", f"--offload-arch={ARCH}", "-ffast-math",
+                *EXTRA_FLAGS.get(src.name, []),
                 "-Wall", "-Wno-unused-function", f"-I{CSRC / 'kernels'}", "-o", str(obj), str(src),
             ]
         )

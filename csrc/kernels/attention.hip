@@ -40,39 +40,41 @@ __device__ __forceinline__ size_t qkv_off(const AttnArgs& p, int b, int s, int w
     return (((static_cast<size_t>(b) * p.S + s) * 3 + which) * p.H + h) * AT_D;
 }
 
-// 64 x 64 tile, row r from `src + r*stride` for r < valid (zeros otherwise), XOR-swizzled 16-byte chunks
-__device__ __forceinline__ void stage_swz(bf16* dst, const bf16* src, size_t stride, int valid, int tid) {
+// Staging of a 64 x 64 tile (row r from `src + r*stride` for r < valid, zeros otherwise) into LDS, either with
+// XOR-swizzled 16-byte chunks (row-major fragment reads) or in a plain padded layout (transposed reads).
+// The same staging split in two, so the global loads of tile t+1 are in flight while tile t is being
+// computed: tile_load right after the barrier that publishes tile t, tile_store_* after the next one.
+struct TileRegs {
+    bf16x8 v[2];
+};
+
+__device__ __forceinline__ TileRegs tile_load(const bf16* src, size_t stride, int valid, int tid) {
     const int chunk = tid & 7, lrow = tid >> 3;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    TileRegs r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = lrow + 32 * i;
-        const bf16x8 v = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
-        *reinterpret_cast<bf16x8*>(dst + row * AT_D + ((chunk ^ (row & 7)) << 3)) = v;
+        r.v[i] = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void tile_store_swz(bf16* dst, const TileRegs& r, int tid) {
+    const int chunk = tid & 7, lrow = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lrow + 32 * i;
+        *reinterpret_cast<bf16x8*>(dst + row * AT_D + ((chunk ^ (row & 7)) << 3)) = r.v[i];
     }
 }
 
-// same tile in a plain padded layout for transposed reads
-__device__ __forceinline__ void stage_pad(bf16* dst, const bf16* src, size_t stride, int valid, int tid) {
+__device__ __forceinline__ void tile_store_pad(bf16* dst, const TileRegs& r, int tid) {
     const int chunk = tid & 7, lrow = tid >> 3;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = lrow + 32 * i;
-        const bf16x8 v = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
-        *reinterpret_cast<bf16x8*>(dst + row * AT_PITCH + chunk * 8) = v;
-    }
-}
-
-__device__ __forceinline__ void stage_both(bf16* dswz, bf16* dpad, const bf16* src, size_t stride, int valid, int tid) {
-    const int chunk = tid & 7, lrow = tid >> 3;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = lrow + 32 * i;
-        const bf16x8 v = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
-        *reinterpret_cast<bf16x8*>(dswz + row * AT_D + ((chunk ^ (row & 7)) << 3)) = v;
-        *reinterpret_cast<bf16x8*>(dpad + row * AT_PITCH + chunk * 8) = v;
+        *reinterpret_cast<bf16x8*>(dst + row * AT_PITCH + chunk * 8) = r.v[i];
     }
 }
 
@@ -102,6 +104,9 @@ __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
     }
     return r;
 }
+
+// 2^x by the bare hardware instruction: arguments here are <= ~8 and results below 2^-126 may flush to zero
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float group_max(float v) {  // across the four 16-lane groups (same lane & 15)
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -138,51 +143,79 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     float m = AT_NEG, l = 0.f;
 
     const int kend = p.causal ? min(p.S, q0 + 64) : p.S;
+    TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
+    TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
     for (int k0 = 0; k0 < kend; k0 += AT_T) {
+        __syncthreads();  // every wave is done with the previous tile
+        tile_store_swz(sK, rk, tid);
+        tile_store_pad(sV, rv, tid);
         __syncthreads();
-        stage_swz(sK, p.qkv + qkv_off(p, b, k0, 1, h), srow, p.S - k0, tid);
-        stage_pad(sV, p.qkv + qkv_off(p, b, k0, 2, h), srow, p.S - k0, tid);
-        __syncthreads();
+        if (k0 + AT_T < kend) {  // next tile: in flight during this tile's MFMAs
+            rk = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 1, h), srow, p.S - k0 - AT_T, tid);
+            rv = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 2, h), srow, p.S - k0 - AT_T, tid);
+        }
         f32x4 s[4];
-        float mx = AT_NEG;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t * 16, ks, lane), qf[ks], s[t], 0, 0, 0);
+        }
+        // Only the last key tile (keys beyond S) and, with a causal mask, the tile on the diagonal need
+        // per-element masking; the branch is uniform for the workgroup.
+        const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T > q0);
+        float mx = AT_NEG;
+        if (masked) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = k0 + t * 16 + g * 4 + e;
-                const bool ok = key < p.S && (!p.causal || key <= qrow);
-                s[t][e] = ok ? s[t][e] * p.scale_log2 : AT_NEG;
-                mx = fmaxf(mx, s[t][e]);
-            }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + t * 16 + g * 4 + e;
+                    const bool ok = key < p.S && (!p.causal || key <= qrow);
+                    s[t][e] = ok ? s[t][e] * p.scale_log2 : AT_NEG;
+                    mx = fmaxf(mx, s[t][e]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[t][e] *= p.scale_log2;
+                    mx = fmaxf(mx, s[t][e]);
+                }
         }
         mx = group_max(mx);
-        const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
+        // The running maximum is raised only when a score exceeds it by more than 2^6: probabilities are then
+        // bounded by 64 instead of 1 (harmless in fp32 / bf16) and the rescaling of the output accumulators,
+        // which costs a round trip through the vector ALU, is skipped for most tiles.  Wave-uniform decision.
+        const bool raise = __any(mx > m + 6.0f);
         float rs = 0.f;
+        if (raise) {
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pv = s[t][e] > 0.5f * AT_NEG ? exp2f(s[t][e] - mn) : 0.f;
+                const float pv = fast_exp2(s[t][e] - m);  // masked scores are -1e30: 2^-huge = 0
                 s[t][e] = pv;
                 rs += pv;
             }
-        rs = group_sum(rs);
-        l = l * alpha + rs;
-        m = mn;
+        l += group_sum(rs);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, kp * 32, dt * 16, lane),
                                                                 pack_pair(s[2 * kp], s[2 * kp + 1]), o[dt], 0, 0, 0);
-        }
     }
     if (qrow < p.S) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -252,17 +285,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int qstart = p.causal ? k0 : 0;  // queries before the first key of this tile never attend to it
-    for (int q0 = qstart; q0 < p.S; q0 += AT_T) {
-        __syncthreads();
-        stage_both(sQ, sQt, p.qkv + qkv_off(p, b, q0, 0, h), srow, p.S - q0, tid);
-        stage_both(sDO, sDOt, p.dout + ((static_cast<size_t>(b) * p.S + q0) * p.H + h) * AT_D, orow, p.S - q0, tid);
+    TileRegs rq, rdo;
+    float r_lse = 0.f, r_delta = 0.f;
+    auto prefetch = [&](int q0) {
+        rq = tile_load(p.qkv + qkv_off(p, b, q0, 0, h), srow, p.S - q0, tid);
+        rdo = tile_load(p.dout + ((static_cast<size_t>(b) * p.S + q0) * p.H + h) * AT_D, orow, p.S - q0, tid);
         if (tid < AT_T) {
             const int qq = q0 + tid;
             const size_t off = (static_cast<size_t>(b) * p.H + h) * p.S + min(qq, p.S - 1);
-            sLse[tid] = qq < p.S ? p.lse[off] * 1.4426950408889634f : 0.f;
-            sDelta[tid] = qq < p.S ? p.delta[off] : 0.f;
+            r_lse = qq < p.S ? p.lse[off] * 1.4426950408889634f : 0.f;
+            r_delta = qq < p.S ? p.delta[off] : 0.f;
+        }
+    };
+    if (qstart < p.S) prefetch(qstart);
+    for (int q0 = qstart; q0 < p.S; q0 += AT_T) {
+        __syncthreads();  // every wave is done with the previous tile
+        tile_store_swz(sQ, rq, tid);
+        tile_store_pad(sQt, rq, tid);
+        tile_store_swz(sDO, rdo, tid);
+        tile_store_pad(sDOt, rdo, tid);
+        if (tid < AT_T) {
+            sLse[tid] = r_lse;
+            sDelta[tid] = r_delta;
         }
         __syncthreads();
+        if (q0 + AT_T < p.S) prefetch(q0 + AT_T);  // in flight during this tile's MFMAs
+        // per-element masking only where it can matter: queries or keys beyond S, the causal diagonal (uniform)
+        const bool masked = (q0 + AT_T > p.S) || (k0 + AT_T > p.S) || (p.causal && q0 < k0 + AT_T);
         f32x4 pt[4], ds[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -272,13 +321,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t * 16, ks, lane), kf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sDO, t * 16, ks, lane), vf[ks], dp, 0, 0, 0);
             }
+            if (masked) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ql = t * 16 + g * 4 + e, qq = q0 + ql;
-                const bool ok = qq < p.S && key < p.S && (!p.causal || key <= qq);
-                const float pv = ok ? exp2f(s[e] * p.scale_log2 - sLse[ql]) : 0.f;
-                pt[t][e] = pv;
-                ds[t][e] = pv * (dp[e] - sDelta[ql]);
+                for (int e = 0; e < 4; ++e) {
+                    const int ql = t * 16 + g * 4 + e, qq = q0 + ql;
+                    const bool ok = qq < p.S && key < p.S && (!p.causal || key <= qq);
+                    const float pv = ok ? fast_exp2(s[e] * p.scale_log2 - sLse[ql]) : 0.f;
+                    pt[t][e] = pv;
+                    ds[t][e] = pv * (dp[e] - sDelta[ql]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ql = t * 16 + g * 4 + e;
+                    const float pv = fast_exp2(s[e] * p.scale_log2 - sLse[ql]);
+                    pt[t][e] = pv;
+                    ds[t][e] = pv * (dp[e] - sDelta[ql]);
+                }
             }
         }
 #pragma unroll
@@ -346,11 +405,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int kend = p.causal ? min(p.S, q0 + 64) : p.S;
+    TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
+    TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
     for (int k0 = 0; k0 < kend; k0 += AT_T) {
+        __syncthreads();  // every wave is done with the previous tile
+        tile_store_swz(sK, rk, tid);
+        tile_store_pad(sKt, rk, tid);
+        tile_store_swz(sV, rv, tid);
         __syncthreads();
-        stage_both(sK, sKt, p.qkv + qkv_off(p, b, k0, 1, h), srow, p.S - k0, tid);
-        stage_swz(sV, p.qkv + qkv_off(p, b, k0, 2, h), srow, p.S - k0, tid);
-        __syncthreads();
+        if (k0 + AT_T < kend) {  // next tile: in flight during this tile's MFMAs
+            rk = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 1, h), srow, p.S - k0 - AT_T, tid);
+            rv = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 2, h), srow, p.S - k0 - AT_T, tid);
+        }
+        const bool masked = (k0 + AT_T > p.S) || (q0 + 64 > p.S) || (p.causal && k0 + AT_T > q0);
         f32x4 ds[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -360,12 +427,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t * 16, ks, lane), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t * 16, ks, lane), dof[ks], dp, 0, 0, 0);
             }
+            if (masked) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = k0 + t * 16 + g * 4 + e;
-                const bool ok = key < p.S && qrow < p.S && (!p.causal || key <= qrow);
-                const float pv = ok ? exp2f(s[e] * p.scale_log2 - lse2) : 0.f;
-                ds[t][e] = pv * (dp[e] - delta);
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + t * 16 + g * 4 + e;
+                    const bool ok = key < p.S && qrow < p.S && (!p.causal || key <= qrow);
+                    const float pv = ok ? fast_exp2(s[e] * p.scale_log2 - lse2) : 0.f;
+                    ds[t][e] = pv * (dp[e] - delta);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ds[t][e] = fast_exp2(s[e] * p.scale_log2 - lse2) * (dp[e] - delta);
             }
         }
 #pragma unroll
