@@ -333,19 +333,22 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // EPI selects what the epilogue reads besides the accumulators: 0 nothing, 1 bias, 2 addend (+ mask bits).
 // It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
 // DMA queue (vmcnt(0)) at its use.
-template <int BM, int BN, int WM, int WN, int NS, int EPI>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const GatherGemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
-    constexpr int AI = (BM / 8) / NW, BI = (BN / 8) / NW;  // LDS-DMA instructions per wave and stage
+    constexpr int PR = 512 / BK;                            // rows per 1 KB DMA piece (8 rows of 128 B or 16 of 64 B)
+    constexpr int CPR = BK / 8;                             // 16-byte chunks per row
+    constexpr int AI = (BM / PR) / NW, BI = (BN / PR) / NW; // LDS-DMA instructions per wave and stage
     constexpr int LPW = AI + BI;
-    constexpr int STAGE = (BM + BN) * GG_BK;               // elements per ring stage: [A tile | B tile]
+    constexpr int STAGE = (BM + BN) * BK;                  // elements per ring stage: [A tile | B tile]
     constexpr int EP = TN;                                 // pitch of the wave-private epilogue rows (chunks XOR-swizzled by row)
     constexpr int CH = TN / 8;                             // 16-byte chunks per epilogue row
     constexpr int RPP = 64 / CH;                           // rows per epilogue pass
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole DMA instructions per wave");
-    static_assert(NS >= 3 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
+    static_assert(BK == 32 || BK == 64, "K-step of 32 or 64");
+    static_assert((BM / PR) % NW == 0 && (BN / PR) % NW == 0, "whole DMA instructions per wave");
+    static_assert(NS >= 2 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
     static_assert(16 % RPP == 0, "epilogue passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);  // [NS][STAGE], then [NW][16][EP]
@@ -359,13 +362,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
     const int my_tiles = (total_tiles - first + G - 1) / G;
-    const int csteps = p.C / GG_BK;
+    const int csteps = p.C / BK;
     const int nsteps = p.T * csteps;
     const int total_steps = my_tiles * nsteps;
 
     // ---- loader: a cursor over (tile, tap, channel block) that runs NS - 1 stages ahead of the MFMAs
-    const int lrow = lane >> 3;                               // row of this lane inside an 8-row DMA piece
-    const int kchunk = ((lane & 7) ^ lrow) << 3;              // swizzled source chunk (rows start at multiples of 8)
+    // Chunk swizzle, applied to the DMA source address and again by the fragment reads.  128-byte rows: chunk ^
+    // (row & 7).  64-byte rows (BK = 32): four rows share a 256-byte bank line, and the lane groups of
+    // ds_read_b128 pair rows {0-3, 12-15} with rows {4-11} of the next chunk; XOR-ing the chunk with
+    // f((row >> 2) & 3), f = {0, 2, 3, 1}, puts the 16 lanes of every group on 16 different 16-byte slots.
+    auto swz = [](int row) { return BK == 64 ? (row & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3); };
+    const int lrow = lane / CPR;                              // row of this lane inside a DMA piece
+    const int kchunk = ((lane % CPR) ^ swz(lrow)) << 3;       // swizzled source chunk (pieces start at multiples of 16 rows)
     int ld_tile = first, ld_t = 0, ld_c0 = 0, ld_issued = 0, ld_slot = 0;
     int a_pix[AI], a_h[AI], a_w[AI];
     int b_off[BI];
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int m = tile_m * BM + (wave * AI + i) * 8 + lrow;
+            const int m = tile_m * BM + (wave * AI + i) * PR + lrow;
             if (m < p.M) {
                 const uint32_t img = fastdiv(m, p.div_ab);
                 const uint32_t rem = m - img * (p.OA * p.OB);
@@ -390,14 +398,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int n = tile_n * BN + (wave * BI + i) * 8 + lrow;
+            const int n = tile_n * BN + (wave * BI + i) * PR + lrow;
             b_off[i] = n < p.N ? n * p.ldb : -1;
         }
     };
     auto issue_stage = [&]() {
         const int dh = p.tap_dh[ld_t], dw = p.tap_dw[ld_t], woff = p.tap_woff[ld_t] + ld_c0 + kchunk;
         bf16* sA = ring + ld_slot * STAGE;
-        bf16* sB = sA + BM * GG_BK;
+        bf16* sB = sA + BM * BK;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int ih = a_h[i] + dh, iw = a_w[i] + dw;
@@ -405,16 +413,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                             static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
             const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.C + ld_c0 + kchunk;
             const bf16* src = ok ? p.A + off : p.zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + (wave * AI + i) * 8 * GG_BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + (wave * AI + i) * PR * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const bf16* src = b_off[i] >= 0 ? p.B + static_cast<uint32_t>(b_off[i] + woff) : p.zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sB + (wave * BI + i) * 8 * GG_BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sB + (wave * BI + i) * PR * BK), 16, 0, 0);
         }
         ++ld_issued;
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
-        ld_c0 += GG_BK;
+        ld_c0 += BK;
         if (ld_c0 >= p.C) {
             ld_c0 = 0;
             if (++ld_t == p.T) {
@@ -428,39 +436,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     f32x4 acc[FM][FN];
     auto compute = [&](int slot) {
         const bf16* sA = ring + slot * STAGE;
-        const bf16* sB = sA + BM * GG_BK;
-        // both 32-deep halves of the K-step have their own fragment registers, so the reads of the second
-        // half are issued under the MFMAs of the first (the schedule is pinned below)
-        bf16x8 fa[2][FM], fb[2][FN];
+        const bf16* sB = sA + BM * BK;
+        // every 32-deep slice of the K-step has its own fragment registers, so the reads of the next slice (or
+        // of the second half of the rows) are issued under the MFMAs of the current one (schedule pinned below)
+        constexpr int KK = BK / 32;
+        bf16x8 fa[KK][FM], fb[KK][FN];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
             const int kc = kk * 4 + (lane >> 4);
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int row = wn * TN + j * 16 + (lane & 15);
-                fb[kk][j] = *reinterpret_cast<const bf16x8*>(sB + row * GG_BK + ((kc ^ (row & 7)) << 3));
+                fb[kk][j] = *reinterpret_cast<const bf16x8*>(sB + row * BK + ((kc ^ swz(row)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int row = wm * TM + i * 16 + (lane & 15);
-                fa[kk][i] = *reinterpret_cast<const bf16x8*>(sA + row * GG_BK + ((kc ^ (row & 7)) << 3));
+                fa[kk][i] = *reinterpret_cast<const bf16x8*>(sA + row * BK + ((kc ^ swz(row)) << 3));
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
-        // schedule: first-half reads | (2 MFMA, 1 read) until the second-half reads are out | remaining MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+        // Pinned schedule.  Reads are issued in the order of the loops above (per 32-deep slice: B fragments, then
+        // A fragments by row block), MFMAs row block by row block; a fragment is read a few MFMA groups before
+        // its use and is dead right after it, which keeps the live fragment registers far below KK * (FM + FN).
+        constexpr int READS = KK * (FM + FN), GROUPS = KK * FM;
+        constexpr int LEAD = FN + 2;                                   // reads issued before the first MFMA
+        constexpr int PER = (READS - LEAD + GROUPS - 2) / (GROUPS - 1) > 1 ? 2 : 1;  // reads after each MFMA group
+        __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0);
 #pragma unroll
-        for (int r = 0; r < FM + FN; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        for (int gi = 0; gi < GROUPS; ++gi) {
+            __builtin_amdgcn_sched_group_barrier(0x008, FN, 0);
+            // (a request beyond the last read simply matches nothing)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (PER == 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * FM * FN - 2 * (FM + FN), 0);
     };
 
     // BatchNorm partial sums of this lane's 8 channels, carried across tiles
@@ -585,11 +600,12 @@ static int pdt_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK>
 static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stream) {
-    constexpr size_t lds = (static_cast<size_t>(NS) * (BM + BN) * GG_BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
+    if ((a.C % BK) != 0) return -1;
+    constexpr size_t lds = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
-    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI>;
+    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -604,12 +620,12 @@ static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stre
     return pdt_launch_status();
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK>
 static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
     if (a.zeros == nullptr || (a.bias != nullptr && a.addend != nullptr)) return -1;
-    if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1>(a, stream);
-    if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2>(a, stream);
-    return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0>(a, stream);
+    if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1, BK>(a, stream);
+    if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2, BK>(a, stream);
+    return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK>(a, stream);
 }
 
 // Host entry.  Shapes are validated here; the kernel assumes them.
@@ -662,6 +678,8 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         case 10: return launch_gather_gemm_ring<128, 128, 4, 2, 4>(a, s);  // 8 waves, 4 stages
         case 13: return launch_gather_gemm_ring<256, 128, 4, 2, 3>(a, s);  // 8 waves, 256-row tile
         case 14: return launch_gather_gemm_ring<256, 64, 8, 1, 3>(a, s);   // narrow N, 32x64 per wave
+        case 15: return launch_gather_gemm_ring<256, 256, 2, 4, 4, 32>(a, s);  // 128x64 per wave, K-step 32, 4 stages
+        case 16: return launch_gather_gemm_ring<256, 256, 2, 4, 2, 64>(a, s);  // 128x64 per wave, K-step 64, 2 stages
         default: return -1;
     }
 }

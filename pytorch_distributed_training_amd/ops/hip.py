@@ -356,9 +356,11 @@ def _num_cus() -> int:
 def _pick_tile(m: int, n: int) -> int:
     """Tile variant of the gather-GEMM kernel for an M x N output.
 
-    0/1/2: one tile per workgroup (128x128, 128x64, 64x64).  13: persistent workgroups streaming 256x128
-    tiles through an LDS-DMA ring; it wins once every CU gets several tiles (measured per layer with
-    bench/conv_bench.py), below that the tail of a partially filled last round costs more than it saves."""
+    0/1/2: one tile per workgroup (128x128, 128x64, 64x64).  13/14/16: persistent workgroups streaming
+    256x128 / 256x64 / 256x256 tiles through an LDS-DMA ring; they win once every CU gets several tiles
+    (measured per layer with bench/conv_bench.py and bench/gemm_bench.py), below that the tail of a partially
+    filled last round costs more than it saves.  The 256x256 tile moves a third less operand data per FLOP
+    through the L2-to-LDS path, which is what bounds the 256x128 kernel on large GEMMs."""
     if n <= 64:
         if m < 128:
             return 2
@@ -367,8 +369,12 @@ def _pick_tile(m: int, n: int) -> int:
         return 14 if -(-m // 256) >= _RING_MIN_TILES else 1  # 256x64 ring once every CU gets several tiles
     if _TILE_WIDE >= 0:
         return _TILE_WIDE
-    tiles = -(-m // 256) * -(-n // 128)
     cus = _num_cus()
+    if n >= 256 and -(-n // 256) * 256 <= 1.15 * n:
+        big = -(-m // 256) * -(-n // 256)
+        if big >= 4 * cus or (big >= cus and big >= 0.85 * -(-big // cus) * cus):
+            return 16
+    tiles = -(-m // 256) * -(-n // 128)
     rounds = -(-tiles // cus)
     if tiles >= _RING_MIN_TILES or (tiles >= cus and tiles >= 0.9 * rounds * cus):
         return 13

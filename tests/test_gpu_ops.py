@@ -81,7 +81,7 @@ RING_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 3, 6, 10, 13])
+@pytest.mark.parametrize("tile", [0, 3, 6, 10, 13, 15, 16])
 @pytest.mark.parametrize("nb,cin,cout,k,stride,pad,hw", RING_CASES)
 def test_conv_every_wide_tile_variant(hip, monkeypatch, tile, nb, cin, cout, k, stride, pad, hw):
     """Each wide-N kernel variant (one tile per workgroup, and the persistent LDS-DMA ring) on its own."""
@@ -97,7 +97,7 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
     test_conv_forward_backward(hip, 6, 256, 64, 1, 1, 0, 56)
 
 
-@pytest.mark.parametrize("tile", [10, 13])
+@pytest.mark.parametrize("tile", [10, 13, 15, 16])
 def test_linear_ring_variant_with_bias(hip, monkeypatch, tile):
     monkeypatch.setattr(hip, "_TILE_WIDE", tile)
     test_linear_forward_backward(hip, 3000, 256, 1000, True)
