@@ -893,7 +893,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     constexpr int LPW = YI + XI;
     constexpr int STAGE = KM * (BN + BC);        // elements: [Y tile | X tile]
     static_assert((KM / YR) % NW == 0 && (KM / XR) % NW == 0, "whole DMA pieces per wave");
-    static_assert(NS >= 3 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NS >= 2 && (NS - 2) * LPW <= 63, "vmcnt is a 6-bit counter");
     static_assert(YR <= 8 && XR <= 8 && BN >= 64 && BC >= 64, "rows of at least 128 bytes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
@@ -999,42 +999,39 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     auto compute = [&](int slot) {
         const uint32_t yb = lds_base + static_cast<uint32_t>(slot * STAGE) * 2u;
         const uint32_t xb = yb + KM * BN * 2u;
-        s16x4 ylo[2][FN], yhi[2][FN], xlo[2][FC], xhi[2][FC];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 2; ++kk) {  // one 32-pixel slice at a time: half the fragment registers
+            s16x4 ylo[FN], yhi[FN], xlo[FC], xhi[FC];
             const int krow = kk * 32 + 4 * g + q;  // krow and krow + 16 swizzle alike
             const int swy = swz_y(krow), swx = swz_x(krow);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const int u = (wr * TN + i * 16) >> 4;
                 const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ swy) << 4) + 4 * pp) * 2u;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[kk][i]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[kk][i]) : "v"(a), "n"(16 * BN * 2) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[i]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[i]) : "v"(a), "n"(16 * BN * 2) : "memory");
             }
 #pragma unroll
             for (int j = 0; j < FC; ++j) {
                 const int u = (wc * TC + j * 16) >> 4;
                 const uint32_t a = xb + static_cast<uint32_t>(krow * BC + ((u ^ swx) << 4) + 4 * pp) * 2u;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kk][j]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[kk][j]) : "v"(a), "n"(16 * BC * 2) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[j]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[j]) : "v"(a), "n"(16 * BC * 2) : "memory");
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-                const s16x8 yv = {ylo[kk][i][0], ylo[kk][i][1], ylo[kk][i][2], ylo[kk][i][3],
-                                  yhi[kk][i][0], yhi[kk][i][1], yhi[kk][i][2], yhi[kk][i][3]};
+                const s16x8 yv = {ylo[i][0], ylo[i][1], ylo[i][2], ylo[i][3], yhi[i][0], yhi[i][1], yhi[i][2], yhi[i][3]};
 #pragma unroll
                 for (int j = 0; j < FC; ++j) {
-                    const s16x8 xv = {xlo[kk][j][0], xlo[kk][j][1], xlo[kk][j][2], xlo[kk][j][3],
-                                      xhi[kk][j][0], xhi[kk][j][1], xhi[kk][j][2], xhi[kk][j][3]};
+                    const s16x8 xv = {xlo[j][0], xlo[j][1], xlo[j][2], xlo[j][3], xhi[j][0], xhi[j][1], xhi[j][2], xhi[j][3]};
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
                                                                          acc[i][j], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
 #pragma unroll
@@ -1156,6 +1153,8 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         return launch_wgrad_ring<256, 128, 4, 2, 3>(a, gy, s);
     } else if (tile == 12) {
         return launch_wgrad_ring<128, 256, 2, 4, 3>(a, gy, s);
+    } else if (tile == 16) {
+        return launch_wgrad_ring<256, 256, 2, 4, 2>(a, gy, s);
     } else if (tile == 13) {
         return launch_wgrad_ring<64, 256, 2, 4, 3>(a, gy, s);
     } else if (tile == 14) {

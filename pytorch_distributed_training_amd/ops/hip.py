@@ -428,13 +428,16 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         tile = 15
     elif WGRAD_RING and N >= 128 and kc >= 128:
         # LDS-DMA ring kernel, one workgroup of 8 waves per CU; the 256-wide side goes to the larger dimension
+        # (a 256 x 256 tile, PDT_WGRAD_RING=16, measured no faster than these: the weight gradient is not bound by
+        # operand traffic the way the forward GEMM is)
         tile = 11 if N >= 256 and N >= kc else (12 if kc >= 256 else 10)
     elif WGRAD_RING and N < 128 and kc >= 192:
         tile = 13  # 64 x 256: all output channels of a narrow layer, several taps per tile
     elif WGRAD_RING and N >= 256 and kc < 128:
         tile = 14  # 256 x 64
     if tile >= 10:
-        bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256), 13: (64, 256), 14: (256, 64), 15: (64, 256)}[tile]
+        bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256), 13: (64, 256), 14: (256, 64), 15: (64, 256),
+                  16: (256, 256)}[tile]
         splits = _wgrad_splits(M, N, kc, 1, bn, bc, WGRAD_RING_TARGET_BLOCKS)
     else:
         tile = 0 if (N > 64 and C > 64 and not smallc) else 1
