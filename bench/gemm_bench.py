@@ -1,7 +1,7 @@
-"""Raw throughput of the MFMA GEMM core (the convolution kernel with a single tap) on square and
-skinny problems, random bf16 operands.
+"""Raw throughput of the MFMA GEMM core (the convolution kernel with a single tap) and of the weight-gradient
+kernel (dW[N][K] = dY[M][N]^T X[M][K]) on square and skinny problems, random bf16 operands.
 
-    python bench/gemm_bench.py
+    python bench/gemm_bench.py [--wgrad-only]
 """
 from __future__ import annotations
 
@@ -18,10 +18,42 @@ SHAPES = [(4096, 4096, 4096), (8192, 8192, 8192), (50176, 256, 2304), (50176, 10
           (8192, 3072, 768), (8192, 50304, 1024)]
 
 
+WGRAD_SHAPES = [(50432, 768, 768), (50432, 2304, 768), (50432, 3072, 768), (50432, 768, 3072), (16384, 1024, 1024),
+                (16384, 4096, 1024), (16384, 1024, 4096), (16384, 50304, 1024), (401408, 512, 128), (100352, 1024, 256)]
+
+
+def _time(run):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    return statistics.median(ts)
+
+
+def wgrad_section(hip, dev):
+    print(f"weight gradient\n{'M':>8}{'N':>7}{'K':>6}{'us':>10}{'TF/s':>8}")
+    for m, n, k in WGRAD_SHAPES:
+        dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
+        x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        dw = torch.zeros(n, k, device=dev)
+        t = _time(lambda: hip._launch_wgrad(dy, x, dw, m, n, n, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1))
+        print(f"{m:8d}{n:7d}{k:6d}{t * 1e6:10.1f}{2.0 * m * n * k / t / 1e12:8.1f}")
+        del dy, x, dw
+
+
 def main():
     from pytorch_distributed_training_amd.ops import hip
 
     dev = torch.device("cuda", 0)
+    if "--wgrad-only" in sys.argv:
+        return wgrad_section(hip, dev)
     print(f"{'M':>8}{'N':>7}{'K':>6}{'us':>10}{'TF/s':>8}")
     for m, n, k in SHAPES:
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
@@ -44,6 +76,8 @@ def main():
             ts.append(e0.elapsed_time(e1) * 1e-3)
         t = statistics.median(ts)
         print(f"{m:8d}{n:7d}{k:6d}{t * 1e6:10.1f}{2.0 * m * n * k / t / 1e12:8.1f}")
+        del a, b, out
+    wgrad_section(hip, dev)
 
 
 if __name__ == "__main__":

@@ -401,7 +401,8 @@ WGRAD_MIN_BLOCKS = int(_os.environ.get("PDT_WGRAD_MIN_BLOCKS", "384"))
 
 
 WGRAD_RING = int(_os.environ.get("PDT_WGRAD_RING", "1"))  # 0: one-step register-staged kernel everywhere
-WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "512"))
+# ring kernels hold one workgroup per CU: one full round of workgroups, not two (twice the atomic volume)
+WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "256"))
 
 
 def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int] = None, target: Optional[int] = None) -> int:
@@ -428,9 +429,10 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         tile = 15
     elif WGRAD_RING and N >= 128 and kc >= 128:
         # LDS-DMA ring kernel, one workgroup of 8 waves per CU; the 256-wide side goes to the larger dimension
-        # (a 256 x 256 tile, PDT_WGRAD_RING=16, measured no faster than these: the weight gradient is not bound by
-        # operand traffic the way the forward GEMM is)
-        tile = 11 if N >= 256 and N >= kc else (12 if kc >= 256 else 10)
+        if N >= 256 and kc >= 256 and N * kc >= 1536 * 1024 and 2 * kc >= N:
+            tile = 16  # 256 x 256: a third less operand traffic per FLOP; pays for the large transformer weights
+        else:
+            tile = 11 if N >= 256 and N >= kc else (12 if kc >= 256 else 10)
     elif WGRAD_RING and N < 128 and kc >= 192:
         tile = 13  # 64 x 256: all output channels of a narrow layer, several taps per tile
     elif WGRAD_RING and N >= 256 and kc < 128:
