@@ -402,7 +402,7 @@ WGRAD_MIN_BLOCKS = int(_os.environ.get("PDT_WGRAD_MIN_BLOCKS", "384"))
 
 WGRAD_RING = int(_os.environ.get("PDT_WGRAD_RING", "1"))  # 0: one-step register-staged kernel everywhere
 # ring kernels hold one workgroup per CU: one full round of workgroups, not two (twice the atomic volume)
-WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "256"))
+WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "0"))  # 0: the number of CUs
 
 
 def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int] = None, target: Optional[int] = None) -> int:
@@ -440,7 +440,7 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
     if tile >= 10:
         bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256), 13: (64, 256), 14: (256, 64), 15: (64, 256),
                   16: (256, 256)}[tile]
-        splits = _wgrad_splits(M, N, kc, 1, bn, bc, WGRAD_RING_TARGET_BLOCKS)
+        splits = _wgrad_splits(M, N, kc, 1, bn, bc, WGRAD_RING_TARGET_BLOCKS or _num_cus())
     else:
         tile = 0 if (N > 64 and C > 64 and not smallc) else 1
         bt = 128 if tile == 0 else 64
