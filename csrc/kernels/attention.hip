@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         // Only the last key tile (keys beyond S) and, with a causal mask, the tile on the diagonal need
         // per-element masking; the branch is uniform for the workgroup.
         const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T > q0);
-        float mx = AT_NEG;
+        float mx = AT_NEG;  // maximum of the raw scores; the softmax scale (> 0) is folded into the exponent's fma
         if (masked) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -173,19 +173,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + t * 16 + g * 4 + e;
                     const bool ok = key < p.S && (!p.causal || key <= qrow);
-                    s[t][e] = ok ? s[t][e] * p.scale_log2 : AT_NEG;
+                    s[t][e] = ok ? s[t][e] : AT_NEG;
                     mx = fmaxf(mx, s[t][e]);
                 }
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[t][e] *= p.scale_log2;
-                    mx = fmaxf(mx, s[t][e]);
-                }
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][e]);
         }
-        mx = group_max(mx);
+        mx = group_max(mx) * p.scale_log2;
         // The running maximum is raised only when a score exceeds it by more than 2^6: probabilities are then
         // bounded by 64 instead of 1 (harmless in fp32 / bf16) and the rescaling of the output accumulators,
         // which costs a round trip through the vector ALU, is skipped for most tiles.  Wave-uniform decision.
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pv = fast_exp2(s[t][e] - m);  // masked scores are -1e30: 2^-huge = 0
+                const float pv = fast_exp2(fmaf(s[t][e], p.scale_log2, -m));  // masked scores are -1e30: 2^-huge = 0
                 s[t][e] = pv;
                 rs += pv;
             }
@@ -232,16 +229,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// delta[b,h,s] = sum_d dO * O   (one wave per (b, s, h) row of 64)
+// delta[b,h,s] = sum_d dO * O   (8 lanes x 16 bytes per (b, s, h) row of 64: a wave reads 8 rows = 1 KB per load)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
     const long long rows = static_cast<long long>(p.B) * p.S * p.H;
-    const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    float v = bf16_to_f32(p.dout[row * AT_D + lane]) * bf16_to_f32(p.o[row * AT_D + lane]);
-    v = wave_sum(v);
-    if (lane == 0) {
+    const long long row = blockIdx.x * 32ll + (threadIdx.x >> 3);
+    const int part = threadIdx.x & 7;
+    float v = 0.f;
+    if (row < rows) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.dout + row * AT_D + part * 8);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(p.o + row * AT_D + part * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v += bf16_to_f32(a[e]) * bf16_to_f32(c[e]);
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (part == 0 && row < rows) {
         const int h = static_cast<int>(row % p.H);
         const long long bs = row / p.H;
         const int s = static_cast<int>(bs % p.S), b = static_cast<int>(bs / p.S);
@@ -497,7 +501,7 @@ PDT_API int pdt_attention_bwd(const void* qkv, const void* o, const void* dout, 
     a.causal = causal;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long rows = static_cast<long long>(B) * S * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(pdt_cdiv(rows, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(pdt_cdiv(rows, 32)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, s, a);
     return pdt_launch_status();
