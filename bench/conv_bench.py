@@ -96,6 +96,7 @@ def main():
             col = None
             link = None
             link_out = None
+            stat_link = None
             needs_input_grad = (False, False, False, False, False)
 
         def dgrad():

@@ -36,6 +36,13 @@ struct GatherGemmArgs {
     const bf16* addend; // tensor with the layout of Out added to the result (residual gradient), or nullptr
     const uint8_t* addend_bits;  // optional ReLU mask for the addend: bit e of byte v gates element 8v + e
     const bf16* zeros;  // >= 16 bytes of zeros (ring variant: source of rows that are padding); may be nullptr otherwise
+    // ring variant, data-gradient launches: the result is the gradient of a BatchNorm(+ReLU) output, and the
+    // per-channel sums BatchNorm's backward needs (sum dz, sum dz * xhat, dz = result * [activation > 0]) are
+    // accumulated here into stats ([slots][3][N]) instead of by a separate pass over the gradient
+    const bf16* bn_y;          // pre-normalisation activations, layout of Out
+    const float* bn_consts;    // [4][N]: mean, rstd, scale, shift
+    const uint8_t* bn_bits;    // ReLU mask bits of the activation (block tails); nullptr: mask = y * scale + shift > 0
+    int stat_rows;             // rows per slot of `stats`: 2 (forward statistics) or 3 (backward sums)
     int M, N, ldb, ldo, C, T;
     int Hin, Win, istr;
     int Hout, Wout, ostr, oph, opw;
@@ -330,7 +337,8 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// EPI selects what the epilogue reads besides the accumulators: 0 nothing, 1 bias, 2 addend (+ mask bits).
+// EPI selects what the epilogue reads besides the accumulators (bit mask): 1 bias, 2 addend (+ mask bits),
+// 4 BatchNorm-backward sums with the ReLU mask recomputed from bn_y, 8 the same with the mask from bn_bits.
 // It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
 // DMA queue (vmcnt(0)) at its use.
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK>
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
         const int ncol = stats_n0 + wn * TN + ech * 8;
         if (lane < CH && ncol < p.N) {
-            float* slot = p.stats + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 2 * p.N;
+            float* slot = p.stats + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * p.stat_rows * p.N;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 __hip_atomic_fetch_add(slot + ncol + e, s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -542,11 +550,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         const int ncol = n0 + wn * TN + ech * 8;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
+            // output pixels of this lane's rows in the 16-row group, and (BatchNorm-backward sums) the loads of the
+            // matching activations, issued first so their latency hides behind the staging round trip below
+            constexpr int NPS = 16 / RPP;
+            size_t pixo[NPS];
+            bool rok[NPS];
+            bf16x8 yv[NPS], av[NPS];
+            unsigned amb[NPS];
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int m = m0 + wm * TM + i * 16 + ps * RPP + erow;
+                rok[ps] = m < p.M && ncol < p.N;
+                const int mc = min(m, p.M - 1);
+                const uint32_t img = fastdiv(mc, p.div_ab);
+                const uint32_t rem = mc - img * (p.OA * p.OB);
+                const uint32_t a = fastdiv(rem, p.div_b);
+                const uint32_t b = rem - a * p.OB;
+                pixo[ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
+                           min(ncol, p.N - 8);
+                if (EPI & 12) yv[ps] = *reinterpret_cast<const bf16x8*>(p.bn_y + pixo[ps]);
+                if (EPI & 2) {
+                    av[ps] = *reinterpret_cast<const bf16x8*>(p.addend + pixo[ps]);
+                    amb[ps] = p.addend_bits != nullptr ? p.addend_bits[pixo[ps] >> 3] : 0xffu;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int nl = j * 16 + (lane >> 4) * 4;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == 1) {
+                if (EPI & 1) {
                     const int n = n0 + wn * TN + nl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bv[e] = p.bias[min(n + e, p.N - 1)];
@@ -558,29 +590,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 *reinterpret_cast<bf16x4*>(epi + er * EP + ((((nl >> 3) ^ er) & (CH - 1)) << 3) + (nl & 4)) = v;
             }
 #pragma unroll
-            for (int ps = 0; ps < 16 / RPP; ++ps) {
+            for (int ps = 0; ps < NPS; ++ps) {
                 const int row = ps * RPP + erow;
-                const int m = m0 + wm * TM + i * 16 + row;
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(epi + row * EP + (((ech ^ row) & (CH - 1)) << 3));
-                if (m < p.M && ncol < p.N) {
-                    const uint32_t img = fastdiv(m, p.div_ab);
-                    const uint32_t rem = m - img * (p.OA * p.OB);
-                    const uint32_t a = fastdiv(rem, p.div_b);
-                    const uint32_t b = rem - a * p.OB;
-                    const size_t pix = (static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw;
-                    if (EPI == 2) {
-                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(p.addend + pix * p.ldo + ncol);
-                        const unsigned mb = p.addend_bits != nullptr ? p.addend_bits[(pix * p.ldo + ncol) >> 3] : 0xffu;
+                if (rok[ps]) {
+                    const size_t o = pixo[ps];
+                    if (EPI & 2) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((mb >> e) & 1u) ? bf16_to_f32(av[e]) : 0.f));
+                            v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((amb[ps] >> e) & 1u) ? bf16_to_f32(av[ps][e]) : 0.f));
                     }
-                    *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
+                    *reinterpret_cast<bf16x8*>(p.Out + o) = v;
+                    if (EPI & 12) {
+                        // BatchNorm-backward sums of the gradient just written (its bf16 value, as a separate pass
+                        // over the stored tensor would see it)
+                        float mu[8], rs[8];
+                        *reinterpret_cast<f32x4*>(mu) = *reinterpret_cast<const f32x4*>(p.bn_consts + ncol);
+                        *reinterpret_cast<f32x4*>(mu + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + ncol + 4);
+                        *reinterpret_cast<f32x4*>(rs) = *reinterpret_cast<const f32x4*>(p.bn_consts + p.N + ncol);
+                        *reinterpret_cast<f32x4*>(rs + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + p.N + ncol + 4);
+                        unsigned mb = 0xffu;
+                        if (EPI & 8) {
+                            mb = p.bn_bits[o >> 3];
+                        } else {
+                            float sc[8], sh[8];
+                            *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + ncol);
+                            *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + ncol + 4);
+                            *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * p.N + ncol);
+                            *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * p.N + ncol + 4);
+                            mb = 0;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = bf16_to_f32(v[e]);
-                        s1[e] += f;
-                        s2[e] += f * f;
+                            for (int e = 0; e < 8; ++e) mb |= ((bf16_to_f32(yv[ps][e]) * sc[e] + sh[e]) > 0.f ? 1u : 0u) << e;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float dz = ((mb >> e) & 1u) ? bf16_to_f32(v[e]) : 0.f;
+                            s1[e] += dz;
+                            s2[e] += dz * (bf16_to_f32(yv[ps][e]) - mu[e]) * rs[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = bf16_to_f32(v[e]);
+                            s1[e] += f;
+                            s2[e] += f * f;
+                        }
                     }
                 }
             }
@@ -623,6 +677,14 @@ static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stre
 template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK>
 static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
     if (a.zeros == nullptr || (a.bias != nullptr && a.addend != nullptr)) return -1;
+    if (a.bn_y != nullptr) {
+        // BatchNorm-backward sums: after a shortcut addend with the mask bits of a block tail, or alone with the
+        // mask recomputed (plain BatchNorm + ReLU between two convolutions)
+        if (a.bias != nullptr || a.stats == nullptr || a.bn_consts == nullptr || a.stat_rows != 3) return -1;
+        if (a.addend != nullptr && a.bn_bits != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 10, BK>(a, stream);
+        if (a.addend == nullptr && a.bn_bits == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 4, BK>(a, stream);
+        return -1;
+    }
     if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1, BK>(a, stream);
     if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2, BK>(a, stream);
     return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK>(a, stream);
@@ -635,7 +697,8 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             const void* addend, const void* addend_bits, int M, int N,
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
-                            const int* tap_woff, int tile, int smallc, const void* zeros, void* stream) {
+                            const int* tap_woff, int tile, int smallc, const void* zeros, const void* bn_y,
+                            const float* bn_consts, const void* bn_bits, void* stream) {
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
     // packed rows: `smallc` is the row width tw; pixels are C (4 or 8) elements apart; B rows cover whole K-steps
@@ -651,6 +714,11 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.addend = static_cast<const bf16*>(addend);
     a.addend_bits = static_cast<const uint8_t*>(addend_bits);
     a.zeros = static_cast<const bf16*>(zeros);
+    a.bn_y = static_cast<const bf16*>(bn_y);
+    a.bn_consts = bn_consts;
+    a.bn_bits = static_cast<const uint8_t*>(bn_bits);
+    a.stat_rows = bn_y != nullptr ? 3 : 2;
+    if (bn_y != nullptr && (smallc || tile < 10)) return -1;  // only the ring kernels have this epilogue
     a.M = M; a.N = N; a.ldb = ldb; a.ldo = ldo; a.C = C; a.T = T;
     a.Hin = Hin; a.Win = Win; a.istr = istr;
     a.Hout = Hout; a.Wout = Wout; a.ostr = ostr; a.oph = oph; a.opw = opw;
@@ -675,10 +743,8 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         case 5: return launch_gather_gemm<128, 64, 4, 2>(a, s);   // 8 waves, 32x32 per wave
         case 6: return launch_gather_gemm<256, 128, 4, 2>(a, s);  // 8 waves, 64x64 per wave
         // ring variants (persistent, LDS-DMA): need the page of zeros
-        case 10: return launch_gather_gemm_ring<128, 128, 4, 2, 4>(a, s);  // 8 waves, 4 stages
         case 13: return launch_gather_gemm_ring<256, 128, 4, 2, 3>(a, s);  // 8 waves, 256-row tile
         case 14: return launch_gather_gemm_ring<256, 64, 8, 1, 3>(a, s);   // narrow N, 32x64 per wave
-        case 15: return launch_gather_gemm_ring<256, 256, 2, 4, 4, 32>(a, s);  // 128x64 per wave, K-step 32, 4 stages
         case 16: return launch_gather_gemm_ring<256, 256, 2, 4, 2, 64>(a, s);  // 128x64 per wave, K-step 64, 2 stages
         default: return -1;
     }

@@ -41,7 +41,7 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
@@ -382,7 +382,12 @@ def _pick_tile(m: int, n: int) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None, smallc=0, addend_bits=None) -> None:
+                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None) -> None:
+    """``bn_stat = (y, consts, bits_or_None)``: also accumulate BatchNorm-backward sums of the result into ``stats``
+    ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`)."""
+    bn_y = bn_consts = bn_bits = None
+    if bn_stat is not None:
+        bn_y, bn_consts, bn_bits = bn_stat
     dh = _int_array([t[0] for t in taps])
     dw = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
@@ -390,7 +395,7 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc),
-                     _zero_page(a.device).data_ptr(), _stream()),
+                     _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _stream()),
         "gather_gemm",
     )
 
@@ -459,6 +464,26 @@ def _conv_out(h: int, k: int, s: int, p: int) -> int:
     return (h + 2 * p - k) // s + 1
 
 
+class StatLink:
+    """Lets the data-gradient kernel of a convolution accumulate the backward sums of the BatchNorm that produced
+    the convolution's input (sum dz, sum dz * xhat per channel), so BatchNorm's backward skips its own
+    reduction pass over that gradient.
+
+    The BatchNorm side fills ``y`` / ``consts`` (and ``bits`` for a block tail, whose ReLU mask is stored) in
+    forward; the convolution side fills ``slots`` in backward when its kernels support it; BatchNorm's backward,
+    which runs next, uses ``slots`` if present and reduces by itself otherwise."""
+
+    __slots__ = ("y", "consts", "bits", "slots")
+
+    def __init__(self):
+        self.y = self.consts = self.bits = self.slots = None
+
+
+def _dgrad_can_fuse_stats(launches) -> bool:
+    """True when every data-gradient launch (M, N) of a convolution runs on a ring kernel."""
+    return bool(launches) and all(_pick_tile(m, n) >= 13 for m, n in launches)
+
+
 class ResidualLink:
     """Carries the shortcut gradient of a residual block from the block-tail backward to the data-gradient
     kernel of the block's first convolution, which adds it in its epilogue.  Both consume the same block
@@ -498,7 +523,7 @@ class _ConvStats(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride: int, padding: int, want_stats: bool, link: Optional[ResidualLink] = None,
-                link_out: Optional[ResidualLink] = None):
+                link_out: Optional[ResidualLink] = None, stat_link: Optional[StatLink] = None):
         x = _as_nhwc(x)
         nb, c, h, w_ = x.shape
         n, c2, r, s = weight.shape
@@ -517,6 +542,7 @@ class _ConvStats(torch.autograd.Function):
         ctx.link = None
         # producer side: usable only if the consuming convolution (called earlier in forward) armed the link
         ctx.link_out = link_out if (link_out is not None and link_out.armed and ctx.needs_input_grad[0]) else None
+        ctx.stat_link = stat_link if (stat_link is not None and stat_link.y is not None and c % 64 == 0) else None
         ctx.set_materialize_grads(False)  # the statistics output never carries a gradient: do not zero-fill one
         if link is not None and c % 64 == 0 and stride == 1 and ctx.needs_input_grad[0]:
             link.armed = True
@@ -555,7 +581,7 @@ class _ConvStats(torch.autograd.Function):
         if ctx.link is not None:
             ctx.link.consumed = True
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dy = _as_nhwc(dy)
         M = nb * ho * wo
         dx = dw = None
@@ -590,6 +616,7 @@ class _ConvStats(torch.autograd.Function):
                 ctx.link.grad = ctx.link.bits = None
                 if addend.shape != dx.shape:
                     raise RuntimeError("residual link carries a gradient of the wrong shape")
+            launches = []
             for ph in range(stride):
                 oa = (h - ph + stride - 1) // stride
                 if oa <= 0:
@@ -606,19 +633,32 @@ class _ConvStats(torch.autograd.Function):
                             if (pw + padding - j) % stride != 0:
                                 continue
                             taps.append(((ph + padding - i) // stride, (pw + padding - j) // stride, (i * s + j) * npad))
-                    _launch_gather_gemm(dy, wt, dx, None, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
-                                        oa, ob, h, w_, stride, ph, pw, addend, addend_bits=addend_bits)
+                    launches.append((oa, ob, ph, pw, taps))
+            # BatchNorm-backward sums of dx in the same kernels, when the producer of x asked for them: a block
+            # tail (mask bits, comes with the shortcut addend) or a plain BatchNorm + ReLU (mask recomputed)
+            bn_stat = slots = None
+            sl = ctx.stat_link
+            if sl is not None and sl.y is not None and sl.y.shape == dx.shape and \
+                    (sl.bits is not None) == (addend is not None) and \
+                    _dgrad_can_fuse_stats([(nb * oa * ob, c) for oa, ob, _, _, _ in launches]):
+                slots = ARENA.alloc((STAT_SLOTS, 3, c), dy.device)
+                bn_stat = (sl.y, sl.consts, sl.bits)
+            for oa, ob, ph, pw, taps in launches:
+                _launch_gather_gemm(dy, wt, dx, slots, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
+                                    oa, ob, h, w_, stride, ph, pw, addend, addend_bits=addend_bits, bn_stat=bn_stat)
+            if bn_stat is not None:
+                sl.slots = slots
         elif ctx.link is not None and ctx.link.grad is not None:
             raise RuntimeError("residual link armed but the convolution input needs no gradient")
         if dx is not None and ctx.link_out is not None and not ctx.link_out.consumed and ctx.link_out.grad is None:
             # the consumer's data-gradient kernel (it runs later: it was created earlier in forward) adds this
             ctx.link_out.grad, ctx.link_out.bits = dx, None
             dx = None
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None, link_out=None):
-    return _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out)
+    return _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out, None)
 
 
 def residual_link():
@@ -665,7 +705,7 @@ def _bn_param_grads(slots, which, count, gamma, beta, consts, c, dev):
 
 
 def _bn_backward(dout, out, y, consts, gamma, beta, count, c, y2=None, consts2=None, gamma2=None, beta2=None,
-                 want_dz=False, mask_mode=None):
+                 want_dz=False, mask_mode=None, slots=None):
     """Shared backward: returns (dy, dgamma, dbeta, extra) where extra = dz | (dy2, dgamma2, dbeta2) | None.
 
     ``mask_mode``: 0 no ReLU, 1 ReLU mask from the stored output, 2 ReLU mask recomputed from ``y`` (plain
@@ -674,9 +714,10 @@ def _bn_backward(dout, out, y, consts, gamma, beta, count, c, y2=None, consts2=N
     M = y.numel() // c
     if mask_mode is None:
         mask_mode = 1 if out is not None else 0
-    slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
-    _check(_bn_bwd_reduce(dout.data_ptr(), _ptr(out), y.data_ptr(), consts.data_ptr(), _ptr(y2), _ptr(consts2),
-                          slots.data_ptr(), M, c, mask_mode, _stream()), "bn_bwd_reduce")
+    if slots is None:  # otherwise the kernel that produced dout has already accumulated the sums
+        slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
+        _check(_bn_bwd_reduce(dout.data_ptr(), _ptr(out), y.data_ptr(), consts.data_ptr(), _ptr(y2), _ptr(consts2),
+                              slots.data_ptr(), M, c, mask_mode, _stream()), "bn_bwd_reduce")
     dgamma, dbeta, coef = _bn_param_grads(slots, 1, count, gamma, beta, consts, c, dev)
     dy = torch.empty_like(y)
     extra = None
@@ -695,7 +736,7 @@ def _bn_backward(dout, out, y, consts, gamma, beta, count, c, y2=None, consts2=N
 
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, bn, relu: bool):
+    def forward(ctx, y, stats, gamma, beta, bn, relu: bool, stat_link: Optional[StatLink] = None):
         y = _as_nhwc(y)
         nb, c, h, w = y.shape
         count = nb * h * w
@@ -705,6 +746,10 @@ class _BnAct(torch.autograd.Function):
                              _stream()), "bn_apply_fwd")
         ctx.save_for_backward(y, consts, gamma, beta)
         ctx.meta = (count, c, relu)
+        ctx.stat_link = None
+        if stat_link is not None and relu and bn.training and ctx.needs_input_grad[0]:
+            stat_link.y, stat_link.consts = y, consts
+            ctx.stat_link = stat_link
         return out
 
     @staticmethod
@@ -712,8 +757,13 @@ class _BnAct(torch.autograd.Function):
         y, consts, gamma, beta = ctx.saved_tensors
         count, c, relu = ctx.meta
         dout = _as_nhwc(dout)
-        dy, dgamma, dbeta, _ = _bn_backward(dout, None, y, consts, gamma, beta, count, c, mask_mode=2 if relu else 0)
-        return dy, None, dgamma, dbeta, None, None
+        slots = None
+        if ctx.stat_link is not None:
+            slots, ctx.stat_link.slots = ctx.stat_link.slots, None
+            ctx.stat_link.y = ctx.stat_link.consts = None
+        dy, dgamma, dbeta, _ = _bn_backward(dout, None, y, consts, gamma, beta, count, c, mask_mode=2 if relu else 0,
+                                            slots=slots)
+        return dy, None, dgamma, dbeta, None, None, None
 
 
 class _BnAddRelu(torch.autograd.Function):
@@ -791,12 +841,13 @@ class _BnReluMaxpool(torch.autograd.Function):
 
 
 def bn_act(y, stats, bn, relu: bool = True):
-    return _BnAct.apply(y, stats, bn.weight, bn.bias, bn, relu)
+    return _BnAct.apply(y, stats, bn.weight, bn.bias, bn, relu, None)
 
 
 def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
-    a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True)
-    return _ConvStats.apply(a, weight, stride, padding, bn.training)
+    sl = StatLink()  # the convolution's data-gradient kernel also reduces for BatchNorm's backward
+    a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True, sl)
+    return _ConvStats.apply(a, weight, stride, padding, bn.training, None, None, sl)
 
 
 def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):

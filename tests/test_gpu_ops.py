@@ -81,7 +81,7 @@ RING_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 3, 6, 10, 13, 15, 16])
+@pytest.mark.parametrize("tile", [0, 3, 6, 13, 16])
 @pytest.mark.parametrize("nb,cin,cout,k,stride,pad,hw", RING_CASES)
 def test_conv_every_wide_tile_variant(hip, monkeypatch, tile, nb, cin, cout, k, stride, pad, hw):
     """Each wide-N kernel variant (one tile per workgroup, and the persistent LDS-DMA ring) on its own."""
@@ -97,7 +97,7 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
     test_conv_forward_backward(hip, 6, 256, 64, 1, 1, 0, 56)
 
 
-@pytest.mark.parametrize("tile", [10, 13, 15, 16])
+@pytest.mark.parametrize("tile", [13, 16])
 def test_linear_ring_variant_with_bias(hip, monkeypatch, tile):
     monkeypatch.setattr(hip, "_TILE_WIDE", tile)
     test_linear_forward_backward(hip, 3000, 256, 1000, True)
@@ -409,9 +409,11 @@ def test_capturable_optimizer_matches_plain_steps():
 
 def test_recorded_step_matches_eager_training():
     """A hipGraph replay of the whole step (zero-grad, forward, backward, optimizer update) does what the eager
-    step does.  SGD keeps the comparison meaningful: fp32 atomics make the summation order, hence the last bits
-    of the gradients, vary between runs, and Adam would turn last-bit noise on near-zero gradient elements
-    into full-size steps of either sign."""
+    step does.  fp32 atomics make the summation order, hence the last bits of the gradients, vary between runs
+    (eager runs differ from each other the same way).  The comparison is kept meaningful by SGD (Adam would turn
+    last-bit noise on near-zero gradient elements into full-size steps of either sign) and by a batch and image
+    size at which no BatchNorm normalises over a handful of values (a 16-sample, 1x1-pixel layer amplifies
+    1e-8 weight differences to 1e-3 loss differences within three steps)."""
     from pytorch_distributed_training_amd import ops
     from pytorch_distributed_training_amd.models import build_model
     from pytorch_distributed_training_amd.optim import FusedOptimizer
@@ -419,12 +421,12 @@ def test_recorded_step_matches_eager_training():
 
     dev = _dev()
     torch.manual_seed(5)
-    xs = [ops.to_device_layout(torch.randn(16, 3, 32, 32, device=dev)) for _ in range(6)]
-    ys = [torch.randint(0, 10, (16,), device=dev) for _ in range(6)]
+    xs = [ops.to_device_layout(torch.randn(48, 3, 64, 64, device=dev)) for _ in range(6)]
+    ys = [torch.randint(0, 10, (48,), device=dev) for _ in range(6)]
 
     def run(graphed: bool):
         torch.manual_seed(6)
-        model = ops.prepare_module(build_model("resnet18", 10, 32).to(dev).to(memory_format=torch.channels_last))
+        model = ops.prepare_module(build_model("resnet18", 10, 64).to(dev).to(memory_format=torch.channels_last))
         opt = FusedOptimizer(model.parameters(), mode="sgd", lr=0.002, momentum=0.9, weight_decay=1e-4)  # a stable trajectory
         opt.zero_grad()
 
@@ -510,3 +512,40 @@ def test_no_kernel_reads_memory_it_did_not_write(monkeypatch):
         loss.backward()
         assert math.isfinite(float(loss.detach()))
         assert all(torch.isfinite(p.grad).all() for p in model.parameters()), name
+
+
+def test_bn_backward_sums_from_the_dgrad_epilogue_match_the_separate_reduction(hip, monkeypatch):
+    """conv(relu(bn(y))): the data-gradient kernels of the convolution accumulate BatchNorm's backward sums
+    (ring kernels only).  Gradients must equal those of the path where BatchNorm reduces by itself."""
+    torch.manual_seed(12)
+    dev = _dev()
+    cases = [(80, 128, 256, 1, 1, 0, 56), (300, 128, 128, 3, 2, 1, 56), (70, 64, 64, 3, 1, 1, 56)]  # rows enough for ring kernels
+    real_reduce, real_can = hip._bn_bwd_reduce, hip._dgrad_can_fuse_stats
+    for nb, cin, cout, k, stride, pad, hw in cases:
+        y = hip.to_device_layout(torch.randn(nb, cin, hw, hw, device=dev))
+        w = nn.Parameter((torch.randn(cout, cin, k, k, device=dev) / math.sqrt(cin * k * k)).contiguous(memory_format=torch.channels_last))
+        gamma, beta = torch.empty(cin, device=dev).uniform_(0.5, 1.5), torch.empty(cin, device=dev).uniform_(-0.5, 0.5)
+        yf = y.float()
+        st = torch.zeros(hip.STAT_SLOTS, 2, cin, device=dev)
+        st[0, 0] = yf.sum(dim=(0, 2, 3))
+        st[0, 1] = (yf * yf).sum(dim=(0, 2, 3))
+        g = None
+        res = {}
+        for fused in (True, False):
+            bn = nn.BatchNorm2d(cin).to(dev)
+            with torch.no_grad():
+                bn.weight.copy_(gamma)
+                bn.bias.copy_(beta)
+            used = []
+            monkeypatch.setattr(hip, "_dgrad_can_fuse_stats", real_can if fused else (lambda launches: False))
+            monkeypatch.setattr(hip, "_bn_bwd_reduce", lambda *a, **kw: (used.append(1), real_reduce(*a, **kw))[1])
+            yy = y.clone().requires_grad_(True)
+            w.grad = None
+            out, _ = hip.bn_relu_conv2d(yy, st.clone(), bn, w, stride, pad)
+            if g is None:
+                g = torch.randn(out.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            out.backward(g)
+            assert (len(used) == 0) == fused, (fused, used)   # the separate reduction ran exactly when not fused
+            res[fused] = (yy.grad.float().clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), w.grad.clone())
+        for a, b in zip(res[True], res[False]):
+            assert _rel_err(a, b) < 2e-3
