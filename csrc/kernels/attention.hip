@@ -123,7 +123,7 @@ __device__ __forceinline__ float group_sum(float v) {
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
     __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_PITCH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 64;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 sDO[AT_T * AT_D];
     __shared__ __attribute__((aligned(16))) bf16 sDOt[AT_T * AT_PITCH];
     __shared__ float sLse[AT_T], sDelta[AT_T];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int k0 = blockIdx.x * 64;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
     __shared__ __attribute__((aligned(16))) bf16 sKt[AT_T * AT_PITCH];
     __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_D];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 64;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
     bf16* sA = reinterpret_cast<bf16*>(smem);
     bf16* sB = sA + BM * GG_BK;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);  // [NS][STAGE], then [NW][16][EP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     bf16* epi = ring + NS * STAGE + wave * 16 * EP;
 
@@ -676,7 +676,7 @@ static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stre
 
 template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK>
 static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
-    if (a.zeros == nullptr || (a.bias != nullptr && a.addend != nullptr)) return -1;
+    if (a.zeros == nullptr) return -1;
     if (a.bn_y != nullptr) {
         // BatchNorm-backward sums: after a shortcut addend with the mask bits of a block tail, or alone with the
         // mask recomputed (plain BatchNorm + ReLU between two convolutions)
@@ -685,6 +685,7 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
         if (a.addend == nullptr && a.bn_bits == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 4, BK>(a, stream);
         return -1;
     }
+    if (a.bias != nullptr && a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 3, BK>(a, stream);
     if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1, BK>(a, stream);
     if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2, BK>(a, stream);
     return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK>(a, stream);
@@ -763,6 +764,7 @@ struct WgradArgs {
     const bf16* X;
     float* dW;
     const bf16* zeros;  // >= 16 bytes of zeros (ring variant)
+    float* dbias;       // ring variant: column sums of dY (the bias gradient) are added here, or nullptr
     int M, N, ldy, C, T, ldw;
     int Hin, Win, istr, OA, OB;
     FastDiv div_ab, div_b, div_c;
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     bf16* sY = reinterpret_cast<bf16*>(smem);  // [2][KM][PITCH]
     bf16* sX = sY + 2 * KM * PITCH;            // [2][KM][PITCH]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (p.N + BT - 1) / BT, tiles_c = (p.C + BT - 1) / BT;
     // All workgroups of one pixel range (every tile and tap) read the same rows of dY and X: give them
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ring = reinterpret_cast<bf16*>(smem);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int KC = p.T * p.C;  // columns of the weight gradient (MODE 1: C is the row width tw)
     const int tiles_c = (KC + BC - 1) / BC;
@@ -1054,6 +1056,17 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Bias gradient = column sums of dY = dY^T * 1: one more MFMA per dY fragment against a fragment of ones.
+    // All workgroups of a row tile and all waves of a wave row see the same dY, so the extra work is dealt
+    // out: column tile tc takes the K-steps s with s % tiles_c == tc, wave column wc the fragments i with
+    // i % WC == wc; everything is added to dbias atomically at the end.
+    const bool do_bias = p.dbias != nullptr;
+    f32x4 accb[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = f32_to_bf16(1.f);
 
     // transposed fragment addressing as in wgrad_kernel: lane (16g + 4q + pp) supplies block row q, columns
     // 4pp..4pp+3; lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3 of each 32-row sub-step.
@@ -1062,7 +1075,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     // is therefore awaited by hand (lgkmcnt(0), then a scheduling fence so no MFMA is hoisted above it).
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_void_t*)ring));
-    auto compute = [&](int slot) {
+    auto compute = [&](int slot, bool bias_step) {
         const uint32_t yb = lds_base + static_cast<uint32_t>(slot * STAGE) * 2u;
         const uint32_t xb = yb + KM * BN * 2u;
 #pragma unroll
@@ -1089,6 +1102,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const s16x8 yv = {ylo[i][0], ylo[i][1], ylo[i][2], ylo[i][3], yhi[i][0], yhi[i][1], yhi[i][2], yhi[i][3]};
+                if (bias_step && (i % WC) == wc)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), ones, accb[i], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < FC; ++j) {
                     const s16x8 xv = {xlo[j][0], xlo[j][1], xlo[j][2], xlo[j][3], xhi[j][0], xhi[j][1], xhi[j][2], xhi[j][3]};
@@ -1104,14 +1119,28 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     for (int k = 0; k < NS - 1; ++k)
         if (ld_issued < nsteps) issue_stage();
     int slot = 0;
+    int bias_turn = do_bias ? tc : -1;  // counts down to this workgroup's next bias K-step
     for (int s = 0; s < nsteps; ++s) {
         if (ld_issued - (s + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
         else wait_vm_and_barrier<0>();
         if (ld_issued < nsteps) issue_stage();
-        compute(slot);
+        const bool bias_step = bias_turn == 0;
+        compute(slot, bias_step);
+        if (do_bias) bias_turn = bias_step ? tiles_c - 1 : bias_turn - 1;
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
 
+    if (do_bias && (lane & 15) == 0) {  // every column of accb holds the same sums: take column 0
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            if ((i % WC) != wc) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wr * TN + i * 16 + (lane >> 4) * 4 + e;
+                if (n < p.N) __hip_atomic_fetch_add(p.dbias + n, accb[i][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     // D[i = n][j = column]: lane holds rows (lane>>4)*4 + e, column lane&15
 #pragma unroll
     for (int j = 0; j < FC; ++j) {
@@ -1154,7 +1183,7 @@ static int launch_wgrad_ring(const WgradArgs& a, int gy, hipStream_t stream) {
 // dW must be zero (or hold a value to accumulate onto) before the call.
 PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
                       int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
-                      int splits, int tile, int smallc, const void* zeros, void* stream) {
+                      int splits, int tile, int smallc, const void* zeros, float* dbias, void* stream) {
     // rows of dY are read in 8-column chunks: ldy must cover N rounded up to 8 (columns >= N are ignored)
     if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8) return -1;
     if (!smallc && (C % 8) != 0) return -1;
@@ -1164,6 +1193,8 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.X = static_cast<const bf16*>(X);
     a.dW = dW;
     a.zeros = static_cast<const bf16*>(zeros);
+    a.dbias = dbias;
+    if (dbias != nullptr && (tile < 10 || tile == 15)) return -1;  // only the MODE 0 ring kernels sum the bias gradient
     a.M = M; a.N = N; a.ldy = ldy; a.C = C; a.T = T; a.ldw = ldw;
     a.Hin = Hin; a.Win = Win; a.istr = istr; a.OA = OA; a.OB = OB;
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);

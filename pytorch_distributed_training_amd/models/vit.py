@@ -26,7 +26,7 @@ class MLP(nn.Module):
 
     def forward(self, x, residual):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, activation="gelu")
-        return ops.add_bias_residual(ops.linear(h, self.fc2.weight, None), self.fc2.bias, residual)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)  # bias and residual in the epilogue
 
 
 class SelfAttention(nn.Module):
@@ -40,7 +40,7 @@ class SelfAttention(nn.Module):
     def forward(self, x, residual):
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)  # [b, s, 3*d], consumed in place by the attention kernel
         o = ops.attention_qkv(qkv, self.heads, causal=self.causal)
-        return ops.add_bias_residual(ops.linear(o, self.proj.weight, None), self.proj.bias, residual)
+        return ops.linear(o, self.proj.weight, self.proj.bias, residual=residual)
 
 
 class EncoderBlock(nn.Module):

@@ -77,10 +77,11 @@ def global_avgpool(a):
     return _ref.global_avgpool(a)
 
 
-def linear(x, weight, bias=None, activation: Optional[str] = None):
+def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None):
+    """act(x W^T + bias) or x W^T + bias + residual (the residual is added in the GEMM epilogue on GPU)."""
     if x.is_cuda:
-        return _hip().linear(x, weight, bias, activation)
-    return _ref.linear(x, weight, bias, activation)
+        return _hip().linear(x, weight, bias, activation, residual)
+    return _ref.linear(x, weight, bias, activation, residual)
 
 
 def softmax_cross_entropy(logits, labels):

@@ -43,7 +43,7 @@ def _sig(name: str, argtypes):
 
 _gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
-_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp])
+_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
@@ -425,7 +425,10 @@ def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int]
     return max(1, min(max(min(want, cap), floor), M // 256))
 
 
-def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=0) -> None:
+def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=0, dbias=None) -> bool:
+    """Launch the weight-gradient kernel.  ``dbias``: fp32 [N] buffer that should also receive the column sums
+    of ``dy`` (the bias gradient); returns True when the chosen kernel did that, False when the caller still
+    has to (only the ring kernels can)."""
     kc = (smallc if smallc else C) * len(taps)  # columns of the weight gradient: flattened (tap, channel) axis
     tile = -1
     if WGRAD_RING >= 10:
@@ -453,11 +456,13 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
     dh = _int_array([t[0] for t in taps])
     dwi = _int_array([t[1] for t in taps])
     wo = _int_array([t[2] for t in taps])
+    fuse_bias = dbias is not None and tile >= 10 and tile != 15
     _check(
         _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
-               wo, splits, tile, int(smallc), _zero_page(dy.device).data_ptr(), _stream()),
+               wo, splits, tile, int(smallc), _zero_page(dy.device).data_ptr(), _ptr(dbias) if fuse_bias else None, _stream()),
         "wgrad",
     )
+    return fuse_bias
 
 
 def _conv_out(h: int, k: int, s: int, p: int) -> int:
@@ -890,8 +895,10 @@ _PADDED_GRADS: Dict[int, int] = {}  # data_ptr of a zero-padded gradient buffer 
 
 
 class _Linear(torch.autograd.Function):
+    """out = x W^T (+ bias) (+ residual), the additions done in the GEMM epilogue."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual=None):
         n, k = weight.shape
         if k % 64 != 0:
             raise ValueError("in_features must be a multiple of 64")
@@ -908,17 +915,27 @@ class _Linear(torch.autograd.Function):
         _check_size(x2)
         wb = SHADOWS.fwd(weight)
         bias_f = bias.detach() if bias is not None else None
-        _launch_gather_gemm(x2, wb, out, None, bias_f, M, n, k, npad, k, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+        addend = None
+        if residual is not None:
+            if npad != n or residual.numel() != M * n:
+                raise ValueError("a fused residual needs out_features % 64 == 0 and the output's shape")
+            addend = residual.reshape(M, n)
+            if addend.dtype != torch.bfloat16:
+                addend = addend.to(torch.bfloat16)
+            if not addend.is_contiguous():
+                addend = addend.contiguous()
+        _launch_gather_gemm(x2, wb, out, None, bias_f, M, n, k, npad, k, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0,
+                            addend=addend)
         ctx.save_for_backward(x2, weight)
         ctx.bias = bias
-        ctx.meta = (lead, n, k, npad, bias is not None)
+        ctx.meta = (lead, n, k, npad, bias is not None, residual is not None)
         res = out[:, :n] if npad != n else out
         return res.reshape(*lead, n) if len(lead) != 1 else res
 
     @staticmethod
     def backward(ctx, g):
         x2, weight = ctx.saved_tensors
-        lead, n, k, npad, has_bias = ctx.meta
+        lead, n, k, npad, has_bias, has_res = ctx.meta
         M = x2.shape[0]
         g2 = g.reshape(M, n)
         if g2.dtype != torch.bfloat16:
@@ -937,23 +954,30 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty((M, k), dtype=torch.bfloat16, device=g.device)
             _launch_gather_gemm(gp, wt, dx, None, None, M, k, npad, k, npad, [(0, 0, 0)], 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
             dx = dx.reshape(*lead, k)
+        # bias gradient: summed by the weight-gradient kernel when it is a ring kernel, else by a column-sum pass
+        want_db = has_bias and ctx.needs_input_grad[2]
+        db_sink = db_buf = None
+        if want_db:
+            db_sink = _grad_sink(ctx.bias, (n,))
+            db_buf = db_sink if db_sink is not None else torch.zeros(n, dtype=torch.float32, device=g.device)
+        bias_done = False
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(weight, (n, k))
             dw = sink if sink is not None else torch.zeros((n, k), dtype=torch.float32, device=g.device)
-            _launch_wgrad(gp, x2, dw, M, n, npad, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1)
+            bias_done = _launch_wgrad(gp, x2, dw, M, n, npad, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1, dbias=db_buf)
             if sink is not None:
                 dw = None
-        if has_bias and ctx.needs_input_grad[2]:
-            sink = _grad_sink(ctx.bias, (n,))
-            db = sink if sink is not None else torch.zeros(n, dtype=torch.float32, device=g.device)
-            _check(_colsum(gp.data_ptr(), db.data_ptr(), M, n, npad, _stream()), "colsum")
-            if sink is not None:
-                db = None
-        return dx, dw, db
+        if want_db:
+            if not bias_done:
+                _check(_colsum(gp.data_ptr(), db_buf.data_ptr(), M, n, npad, _stream()), "colsum")
+            db = None if db_sink is not None else db_buf
+        return dx, dw, db, (g if has_res else None)
 
 
-def linear(x, weight, bias=None, activation: Optional[str] = None):
-    out = _Linear.apply(x, weight, bias)
+def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None):
+    if activation is not None and residual is not None:
+        raise ValueError("an activation and a residual cannot be fused into the same linear layer")
+    out = _Linear.apply(x, weight, bias, residual)
     if activation == "gelu":
         return gelu(out)
     if activation == "relu":

@@ -60,8 +60,10 @@ def global_avgpool(a: torch.Tensor) -> torch.Tensor:
     return a.mean(dim=(2, 3))
 
 
-def linear(x, weight, bias=None, activation: Optional[str] = None):
+def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None):
     out = F.linear(x, weight, bias)
+    if residual is not None:
+        out = out + residual
     if activation == "gelu":
         out = F.gelu(out, approximate="tanh")
     elif activation == "relu":

@@ -103,6 +103,35 @@ def test_linear_ring_variant_with_bias(hip, monkeypatch, tile):
     test_linear_forward_backward(hip, 3000, 256, 1000, True)
 
 
+@pytest.mark.parametrize("m,k,n,wide", [(4096, 1024, 1024, None), (197 * 16, 768, 768, None), (3000, 256, 1024, 13), (3000, 256, 1024, 16), (500, 3072, 768, 0)])
+def test_linear_with_bias_and_residual_in_the_epilogue(hip, monkeypatch, m, k, n, wide):
+    """x W^T + bias + residual from one GEMM; the bias gradient comes out of the weight-gradient kernel when it
+    is a ring kernel (large shapes) and out of the column-sum kernel otherwise."""
+    if wide is not None:
+        monkeypatch.setattr(hip, "_TILE_WIDE", wide)
+    torch.manual_seed(3)
+    dev = _dev()
+    x = torch.randn(m, k, device=dev)
+    res = torch.randn(m, n, device=dev)
+    lin = nn.Linear(k, n).to(dev)
+    xb = x.to(torch.bfloat16).requires_grad_(True)
+    rb = res.to(torch.bfloat16).requires_grad_(True)
+    out = hip.linear(xb, lin.weight, lin.bias, None, rb)
+    xr = _bf16_round(x).requires_grad_(True)
+    rr = _bf16_round(res).requires_grad_(True)
+    wr = _bf16_round(lin.weight.detach()).requires_grad_(True)
+    br = lin.bias.detach().clone().requires_grad_(True)
+    ref = F.linear(xr, wr, br) + rr
+    assert _rel_err(out, ref) < 8e-3
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(_bf16_round(g))
+    assert _rel_err(xb.grad, xr.grad) < 8e-3
+    assert _rel_err(rb.grad, rr.grad) < 1e-6
+    assert _rel_err(lin.weight.grad, wr.grad) < 8e-3
+    assert _rel_err(lin.bias.grad, br.grad) < 8e-3
+
+
 @pytest.mark.parametrize("m,k,n,bias", [(256, 2048, 1000, True), (64, 512, 10, True), (300, 768, 3072, False), (197 * 4, 768, 768, True)])
 def test_linear_forward_backward(hip, m, k, n, bias):
     torch.manual_seed(1)
