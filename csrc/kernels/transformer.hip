@@ -59,39 +59,65 @@ PDT_API int pdt_layernorm_fwd(const void* x, const float* gamma, const float* be
     return pdt_launch_status();
 }
 
-// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
-// Each wave walks rows row0, row0 + stride, ...; a lane always owns the same columns, so it keeps its
-// dgamma/dbeta partial sums in registers (MAXV vectors of 8 columns), combined per workgroup in LDS
-// and added to the zero-initialised fp32 outputs with one atomic per column.
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ addend);  dgamma += dy*xhat;  dbeta += dy
+// Each wave walks rows row0, row0 + stride, ...; a lane always owns the same columns, so it keeps gamma and its
+// dgamma/dbeta partial sums in registers (MAXV vectors of 8 columns), combined per workgroup in LDS and added
+// to the zero-initialised fp32 outputs with one atomic per column.  A row's dy and x stay in registers between
+// the reduction and the output pass (rows of up to 2048 columns), so each is read from memory once.
+// `addend` (optional) is a second gradient of the same input - the skip connection around the normalised
+// branch - added here instead of by a separate element-wise pass.
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, bf16* __restrict__ dx,
-                                                           float* dgamma, float* dbeta, int rows, int D) {
+                                                           const float* __restrict__ rstd, const bf16* __restrict__ addend,
+                                                           bf16* __restrict__ dx, float* dgamma, float* dbeta, int rows, int D) {
+    constexpr bool KEEP = MAXV <= 4;
+    constexpr int NK = KEEP ? MAXV : 1;
     extern __shared__ float sred[];  // [2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
-    float ag[MAXV][8], ab[MAXV][8];
+    float ag[MAXV][8], ab[MAXV][8], gm[NK][8];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) ag[i][e] = ab[i][e] = 0.f;
+    if (KEEP) {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int v = lane + 64 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[i][e] = v < nv ? gamma[v * 8 + e] : 0.f;
+        }
+    }
     for (int idx = threadIdx.x; idx < 2 * D; idx += 256) sred[idx] = 0.f;
     __syncthreads();
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const bf16* dyr = dy + static_cast<size_t>(row) * D;
         const bf16* xr = x + static_cast<size_t>(row) * D;
+        const bf16* ar = addend != nullptr ? addend + static_cast<size_t>(row) * D : nullptr;
+        bf16x8 dk[NK], xk[NK], ak[NK];
+        if (KEEP) {  // all of the row's loads in flight before the first use
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int v = lane + 64 * i;
+                if (v < nv) {
+                    dk[i] = *reinterpret_cast<const bf16x8*>(dyr + v * 8);
+                    xk[i] = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+                    if (ar != nullptr) ak[i] = *reinterpret_cast<const bf16x8*>(ar + v * 8);
+                }
+            }
+        }
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int v = lane + 64 * i;
             if (v < nv) {
-                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dyr + v * 8);
-                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+                const bf16x8 dv = KEEP ? dk[i] : *reinterpret_cast<const bf16x8*>(dyr + v * 8);
+                const bf16x8 xv = KEEP ? xk[i] : *reinterpret_cast<const bf16x8*>(xr + v * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float g = gamma[v * 8 + e];
+                    const float g = KEEP ? gm[i][e] : gamma[v * 8 + e];
                     const float d = bf16_to_f32(dv[e]), xh = (bf16_to_f32(xv[e]) - mu) * rs;
                     c1 += d * g * xh;
                     c2 += d * g;
@@ -107,14 +133,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         for (int i = 0; i < MAXV; ++i) {
             const int v = lane + 64 * i;
             if (v < nv) {
-                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dyr + v * 8);
-                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+                const bf16x8 dv = KEEP ? dk[i] : *reinterpret_cast<const bf16x8*>(dyr + v * 8);
+                const bf16x8 xv = KEEP ? xk[i] : *reinterpret_cast<const bf16x8*>(xr + v * 8);
+                bf16x8 av;
+                if (ar != nullptr) av = KEEP ? ak[i] : *reinterpret_cast<const bf16x8*>(ar + v * 8);
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float g = gamma[v * 8 + e];
+                    const float g = KEEP ? gm[i][e] : gamma[v * 8 + e];
                     const float xh = (bf16_to_f32(xv[e]) - mu) * rs;
-                    o[e] = f32_to_bf16(rs * (bf16_to_f32(dv[e]) * g - c2 - xh * c1));
+                    float r = rs * (bf16_to_f32(dv[e]) * g - c2 - xh * c1);
+                    if (ar != nullptr) r += bf16_to_f32(av[e]);
+                    o[e] = f32_to_bf16(r);
                 }
                 *reinterpret_cast<bf16x8*>(dxr + v * 8) = o;
             }
@@ -138,18 +168,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     }
 }
 
-// dgamma / dbeta must be zero-initialised.
+// dgamma / dbeta must be zero-initialised (or hold a running sum).  addend: optional bf16 [rows, D] added to dx.
 PDT_API int pdt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                              void* dx, float* dgamma, float* dbeta, int rows, int D, void* stream) {
+                              void* dx, float* dgamma, float* dbeta, int rows, int D, const void* addend, void* stream) {
     if (rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * 64 * 8) return -1;
     const int nv = D / 8, maxv = (nv + 63) / 64;
     int grid = pdt_cdiv(rows, 4);
-    if (grid > 512) grid = 512;
+    const int cap = maxv <= 2 ? 1280 : 768;  // workgroups that are resident together at this register footprint
+    if (grid > cap) grid = cap;
     const size_t lds = 2ull * D * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bf16 *pdy = static_cast<const bf16*>(dy), *px = static_cast<const bf16*>(x);
+    const bf16 *pdy = static_cast<const bf16*>(dy), *px = static_cast<const bf16*>(x), *pa = static_cast<const bf16*>(addend);
     bf16* pdx = static_cast<bf16*>(dx);
-#define PDT_LN(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), lds, s, pdy, px, gamma, mean, rstd, pdx, dgamma, dbeta, rows, D)
+#define PDT_LN(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), lds, s, pdy, px, gamma, mean, rstd, pa, pdx, dgamma, dbeta, rows, D)
     if (maxv <= 1) PDT_LN(1);
     else if (maxv <= 2) PDT_LN(2);
     else if (maxv <= 4) PDT_LN(4);

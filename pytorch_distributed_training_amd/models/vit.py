@@ -24,9 +24,9 @@ class MLP(nn.Module):
         self.fc1 = nn.Linear(dim, hidden)
         self.fc2 = nn.Linear(hidden, dim)
 
-    def forward(self, x, residual):
+    def forward(self, x, residual, link=None):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, activation="gelu")
-        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)  # bias and residual in the epilogue
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, link=link)  # both added in the epilogue
 
 
 class SelfAttention(nn.Module):
@@ -37,10 +37,10 @@ class SelfAttention(nn.Module):
         self.qkv = nn.Linear(dim, 3 * dim)
         self.proj = nn.Linear(dim, dim)
 
-    def forward(self, x, residual):
+    def forward(self, x, residual, link=None):
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)  # [b, s, 3*d], consumed in place by the attention kernel
         o = ops.attention_qkv(qkv, self.heads, causal=self.causal)
-        return ops.linear(o, self.proj.weight, self.proj.bias, residual=residual)
+        return ops.linear(o, self.proj.weight, self.proj.bias, residual=residual, link=link)
 
 
 class EncoderBlock(nn.Module):
@@ -52,8 +52,11 @@ class EncoderBlock(nn.Module):
         self.mlp = MLP(dim, mlp_dim)
 
     def forward(self, x):
-        x = self.attn(ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps), x)
-        return self.mlp(ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps), x)
+        # each branch's skip gradient is handed to the LayerNorm at its head (ops.skip_link)
+        l1 = ops.skip_link(x)
+        x = self.attn(ops.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps, link=l1), x, l1)
+        l2 = ops.skip_link(x)
+        return self.mlp(ops.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps, link=l2), x, l2)
 
 
 class VisionTransformer(nn.Module):

@@ -77,10 +77,19 @@ def global_avgpool(a):
     return _ref.global_avgpool(a)
 
 
-def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None):
-    """act(x W^T + bias) or x W^T + bias + residual (the residual is added in the GEMM epilogue on GPU)."""
+def skip_link(x):
+    """Token shared by the LayerNorm at the head of a pre-norm residual branch and the linear layer that closes
+    the branch with ``residual=x``: ``linear(f(layer_norm(x, ..., link=L)), ..., residual=x, link=L)``.  On GPU
+    the skip connection's gradient is then added inside the LayerNorm backward kernel instead of by a separate
+    element-wise pass.  Both ops must see the same ``x``.  ``None`` (no effect) for CPU tensors."""
+    return _hip().skip_link() if x.is_cuda else None
+
+
+def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None, link=None):
+    """act(x W^T + bias) or x W^T + bias + residual (the residual is added in the GEMM epilogue on GPU).
+    ``link``: see :func:`skip_link`."""
     if x.is_cuda:
-        return _hip().linear(x, weight, bias, activation, residual)
+        return _hip().linear(x, weight, bias, activation, residual, link)
     return _ref.linear(x, weight, bias, activation, residual)
 
 
@@ -90,9 +99,9 @@ def softmax_cross_entropy(logits, labels):
     return _ref.softmax_cross_entropy(logits, labels)
 
 
-def layer_norm(x, weight, bias, eps: float = 1e-5):
+def layer_norm(x, weight, bias, eps: float = 1e-5, link=None):
     if x.is_cuda:
-        return _hip().layer_norm(x, weight, bias, eps)
+        return _hip().layer_norm(x, weight, bias, eps, link)
     return _ref.layer_norm(x, weight, bias, eps)
 
 

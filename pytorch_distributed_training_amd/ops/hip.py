@@ -898,7 +898,7 @@ class _Linear(torch.autograd.Function):
     """out = x W^T (+ bias) (+ residual), the additions done in the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual=None):
+    def forward(ctx, x, weight, bias, residual=None, link=None):
         n, k = weight.shape
         if k % 64 != 0:
             raise ValueError("in_features must be a multiple of 64")
@@ -929,6 +929,10 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, weight)
         ctx.bias = bias
         ctx.meta = (lead, n, k, npad, bias is not None, residual is not None)
+        # the skip gradient travels through the link only when the LayerNorm at the head of the branch is going
+        # to run its backward (and so collect it)
+        ctx.link = link if (link is not None and residual is not None and link.armed) else None
+        ctx.res_shape = residual.shape if residual is not None else None
         res = out[:, :n] if npad != n else out
         return res.reshape(*lead, n) if len(lead) != 1 else res
 
@@ -971,13 +975,16 @@ class _Linear(torch.autograd.Function):
             if not bias_done:
                 _check(_colsum(gp.data_ptr(), db_buf.data_ptr(), M, n, npad, _stream()), "colsum")
             db = None if db_sink is not None else db_buf
-        return dx, dw, db, (g if has_res else None)
+        if ctx.link is not None:
+            ctx.link.grad = gp.view(ctx.res_shape)  # npad == n here: gp is the contiguous bf16 gradient
+            return dx, dw, db, None, None
+        return dx, dw, db, (g if has_res else None), None
 
 
-def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None):
+def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None, link=None):
     if activation is not None and residual is not None:
         raise ValueError("an activation and a residual cannot be fused into the same linear layer")
-    out = _Linear.apply(x, weight, bias, residual)
+    out = _Linear.apply(x, weight, bias, residual, link)
     if activation == "gelu":
         return gelu(out)
     if activation == "relu":
@@ -1135,10 +1142,16 @@ def note_parameters_updated(plan: MultiTensorPlan) -> None:
 # ------------------------------------------------------------------------------------------------
 # Transformer operators (LayerNorm, GELU, attention, embedding, bias+residual)
 # ------------------------------------------------------------------------------------------------
-def layer_norm(x, weight, bias, eps: float = 1e-5):
+def layer_norm(x, weight, bias, eps: float = 1e-5, link=None):
     from . import hip_transformer as ht
 
-    return ht.layer_norm(x, weight, bias, eps)
+    return ht.layer_norm(x, weight, bias, eps, link)
+
+
+def skip_link():
+    from . import hip_transformer as ht
+
+    return ht.GradLink()
 
 
 def gelu(x):

@@ -26,7 +26,7 @@ def _sig(name, argtypes):
 
 
 _ln_fwd = _sig("pdt_layernorm_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp])
-_ln_bwd = _sig("pdt_layernorm_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp])
+_ln_bwd = _sig("pdt_layernorm_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp])
 _gelu_fwd = _sig("pdt_gelu_fwd", [_vp, _vp, _ll, _vp])
 _gelu_bwd = _sig("pdt_gelu_bwd", [_vp, _vp, _vp, _ll, _vp])
 _bias_res = _sig("pdt_bias_residual", [_vp, _vp, _vp, _vp, _ll, _i, _vp])
@@ -42,9 +42,28 @@ def _bf16c(x: torch.Tensor) -> torch.Tensor:
     return x if x.is_contiguous() else x.contiguous()
 
 
+class GradLink:
+    """Carries the gradient of a skip connection around a normalised branch to the LayerNorm at the branch's
+    head: ``y = linear(f(layer_norm(x, link=L)), residual=x, link=L)``.  The linear's backward leaves the
+    gradient of ``residual`` (its incoming gradient, unchanged) here instead of returning it, and the
+    LayerNorm backward - which always runs later, being upstream of the linear - adds it to its own input
+    gradient in the same kernel, so autograd never has to sum the two with a separate pass.  ``armed`` is set
+    by the LayerNorm forward only when its backward is going to run."""
+
+    __slots__ = ("grad", "armed")
+
+    def __init__(self):
+        self.grad = None
+        self.armed = False
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float):
+    def forward(ctx, x, weight, bias, eps: float, link=None):
+        ctx.link = link
+        if link is not None:
+            link.armed = bool(ctx.needs_input_grad[0])
+            link.grad = None
         x = _bf16c(x)
         d = x.shape[-1]
         rows = x.numel() // d
@@ -71,15 +90,21 @@ class _LayerNorm(torch.autograd.Function):
         else:
             sw = sb = None
             dg, db = torch.zeros((2, d), dtype=torch.float32, device=x.device).unbind(0)
+        addend = None
+        if ctx.link is not None and ctx.link.grad is not None:
+            addend = ctx.link.grad
+            ctx.link.grad = None
+            if addend.shape != x.shape or addend.dtype != torch.bfloat16 or not addend.is_contiguous():
+                raise RuntimeError("the linked skip gradient does not match the LayerNorm input")
         _check(_ln_bwd(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                       dg.data_ptr(), db.data_ptr(), rows, d, _stream()), "layernorm_bwd")
+                       dg.data_ptr(), db.data_ptr(), rows, d, _ptr(addend), _stream()), "layernorm_bwd")
         if sw is not None:
-            return dx, None, None, None
-        return dx, dg, db, None
+            return dx, None, None, None, None
+        return dx, dg, db, None, None
 
 
-def layer_norm(x, weight, bias, eps: float = 1e-5):
-    return _LayerNorm.apply(x, weight, bias, eps)
+def layer_norm(x, weight, bias, eps: float = 1e-5, link=None):
+    return _LayerNorm.apply(x, weight, bias, eps, link)
 
 
 class _Gelu(torch.autograd.Function):

@@ -60,7 +60,7 @@ def global_avgpool(a: torch.Tensor) -> torch.Tensor:
     return a.mean(dim=(2, 3))
 
 
-def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None):
+def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None, link=None):
     out = F.linear(x, weight, bias)
     if residual is not None:
         out = out + residual
@@ -77,7 +77,7 @@ def softmax_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.T
     return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), labels.reshape(-1))
 
 
-def layer_norm(x, weight, bias, eps: float = 1e-5):
+def layer_norm(x, weight, bias, eps: float = 1e-5, link=None):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 

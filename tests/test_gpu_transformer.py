@@ -3,6 +3,7 @@ import math
 
 import pytest
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -168,3 +169,52 @@ def test_gradient_sinks_match_autograd_accumulation():
         a, b = grads[True][n], grads[False][n]
         assert torch.isfinite(a).all()
         assert _rel(a, b) < 2e-3, n
+
+
+@pytest.mark.parametrize("rows,d", [(197 * 8, 768), (1024, 1024), (300, 2048), (64, 4096)])
+def test_skip_gradient_is_added_inside_the_layernorm_backward(ht, rows, d):
+    """y = linear(layer_norm(x), residual=x) with the skip link: x.grad must equal plain autograd's sum of the
+    branch gradient and the skip gradient."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.ops import reference as ref
+
+    torch.manual_seed(5)
+    dev = torch.device("cuda", 0)
+    ln = nn.LayerNorm(d).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.2, 0.2)
+    lin = nn.Linear(d, d).to(dev)
+    x0 = torch.randn(2, rows // 2, d, device=dev)
+    g = torch.randn(2, rows // 2, d, device=dev).to(torch.bfloat16)
+
+    xa = x0.to(torch.bfloat16).requires_grad_(True)
+    link = ops.skip_link(xa)
+    ya = ops.linear(ops.layer_norm(xa, ln.weight, ln.bias, ln.eps, link=link), lin.weight, lin.bias, residual=xa, link=link)
+    ya.backward(g)
+    assert link.grad is None  # consumed by the LayerNorm backward
+    got = {"x": xa.grad.float(), "lnw": ln.weight.grad.clone(), "lnb": ln.bias.grad.clone(), "w": lin.weight.grad.clone()}
+    for p_ in list(ln.parameters()) + list(lin.parameters()):
+        p_.grad = None
+
+    xb = x0.to(torch.bfloat16).float().requires_grad_(True)
+    wr = lin.weight.detach().to(torch.bfloat16).float()
+    yb = ref.linear(ref.layer_norm(xb, ln.weight, ln.bias, ln.eps), wr, lin.bias, residual=xb)
+    yb.backward(g.float())
+    assert _rel(ya, yb) < 1e-2
+    assert _rel(got["x"], xb.grad) < 1e-2
+    assert _rel(got["lnw"], ln.weight.grad) < 2e-2
+    assert _rel(got["lnb"], ln.bias.grad) < 2e-2
+
+
+def test_skip_link_is_bypassed_when_the_layernorm_input_needs_no_gradient(ht):
+    from pytorch_distributed_training_amd import ops
+
+    dev = torch.device("cuda", 0)
+    d = 256
+    ln, lin = nn.LayerNorm(d).to(dev), nn.Linear(d, d).to(dev)
+    x = torch.randn(128, d, device=dev).to(torch.bfloat16)  # no grad needed
+    link = ops.skip_link(x)
+    y = ops.linear(ops.layer_norm(x, ln.weight, ln.bias, ln.eps, link=link), lin.weight, lin.bias, residual=x, link=link)
+    y.float().sum().backward()
+    assert not link.armed and link.grad is None and lin.weight.grad is not None
