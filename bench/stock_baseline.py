@@ -56,6 +56,8 @@ def main():
     ops.attention_qkv = sdpa_qkv
     ops.residual_link = lambda x: None
     ops.skip_link = lambda x: None
+    ops.gelu_mlp = lambda x, w1, b1, w2, b2, residual=None, link=None: ref.linear(
+        ref.linear(x, w1, b1, activation="gelu"), w2, b2, residual=residual)
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)

@@ -50,6 +50,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// tanh-form GELU through the logistic function: 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)),
+// u = sqrt(2/pi) (x + 0.044715 x^3).  One exp2 and one reciprocal per element.
+__device__ __forceinline__ float pdt_gelu_sigmoid(float x, float x2) {
+    const float u2 = -2.f * 1.4426950408889634f * 0.7978845608028654f * x * (1.f + 0.044715f * x2);  // -2u log2(e)
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u2));
+}
+__device__ __forceinline__ float pdt_gelu(float x) { return x * pdt_gelu_sigmoid(x, x * x); }
+__device__ __forceinline__ float pdt_gelu_grad(float x) {
+    const float x2 = x * x;
+    const float s = pdt_gelu_sigmoid(x, x2);
+    const float du2 = 2.f * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+    return s + x * s * (1.f - s) * du2;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -43,6 +43,11 @@ struct GatherGemmArgs {
     const float* bn_consts;    // [4][N]: mean, rstd, scale, shift
     const uint8_t* bn_bits;    // ReLU mask bits of the activation (block tails); nullptr: mask = y * scale + shift > 0
     int stat_rows;             // rows per slot of `stats`: 2 (forward statistics) or 3 (backward sums)
+    // activation fused into the epilogue: 1 = also store gelu(result) to out2 (Out keeps the pre-activation for the
+    // backward pass); 2 = multiply the result by gelu'(act_src), act_src being that pre-activation (layout of Out)
+    int act;
+    bf16* out2;
+    const bf16* act_src;
     int M, N, ldb, ldo, C, T;
     int Hin, Win, istr;
     int Hout, Wout, ostr, oph, opw;
@@ -261,7 +266,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
                 for (int e = 0; e < 8; ++e)
                     v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((mb >> e) & 1u) ? bf16_to_f32(av[e]) : 0.f));
             }
+            if (p.act == 2) {
+                const bf16x8 hv = *reinterpret_cast<const bf16x8*>(p.act_src + pix * p.ldo + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(hv[e])));
+            }
             *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
+            if (p.act == 1) {
+                bf16x8 gv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] = f32_to_bf16(pdt_gelu(bf16_to_f32(v[e])));
+                *reinterpret_cast<bf16x8*>(p.out2 + pix * p.ldo + ncol) = gv;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = bf16_to_f32(v[e]);
@@ -338,7 +354,8 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 }
 
 // EPI selects what the epilogue reads besides the accumulators (bit mask): 1 bias, 2 addend (+ mask bits),
-// 4 BatchNorm-backward sums with the ReLU mask recomputed from bn_y, 8 the same with the mask from bn_bits.
+// 4 BatchNorm-backward sums with the ReLU mask recomputed from bn_y, 8 the same with the mask from bn_bits,
+// 16 result times gelu'(act_src), 32 gelu(result) stored to out2 as well.
 // It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
 // DMA queue (vmcnt(0)) at its use.
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK>
@@ -569,6 +586,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 pixo[ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
                            min(ncol, p.N - 8);
                 if (EPI & 12) yv[ps] = *reinterpret_cast<const bf16x8*>(p.bn_y + pixo[ps]);
+                if (EPI & 16) yv[ps] = *reinterpret_cast<const bf16x8*>(p.act_src + pixo[ps]);
                 if (EPI & 2) {
                     av[ps] = *reinterpret_cast<const bf16x8*>(p.addend + pixo[ps]);
                     amb[ps] = p.addend_bits != nullptr ? p.addend_bits[pixo[ps] >> 3] : 0xffu;
@@ -600,8 +618,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                         for (int e = 0; e < 8; ++e)
                             v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((amb[ps] >> e) & 1u) ? bf16_to_f32(av[ps][e]) : 0.f));
                     }
+                    if (EPI & 16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(yv[ps][e])));
+                    }
                     *reinterpret_cast<bf16x8*>(p.Out + o) = v;
-                    if (EPI & 12) {
+                    if (EPI & 32) {
+                        bf16x8 gv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gv[e] = f32_to_bf16(pdt_gelu(bf16_to_f32(v[e])));
+                        *reinterpret_cast<bf16x8*>(p.out2 + o) = gv;
+                    }
+                    if (EPI & 48) {
+                        // linear layers: no channel statistics
+                    } else if (EPI & 12) {
                         // BatchNorm-backward sums of the gradient just written (its bf16 value, as a separate pass
                         // over the stored tensor would see it)
                         float mu[8], rs[8];
@@ -677,6 +707,12 @@ static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stre
 template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK>
 static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
     if (a.zeros == nullptr) return -1;
+    if (a.act != 0) {
+        if (a.bn_y != nullptr || a.addend != nullptr || a.stats != nullptr) return -1;
+        if (a.act == 1 && a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 33, BK>(a, stream);
+        if (a.act == 2 && a.bias == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 16, BK>(a, stream);
+        return -1;
+    }
     if (a.bn_y != nullptr) {
         // BatchNorm-backward sums: after a shortcut addend with the mask bits of a block tail, or alone with the
         // mask recomputed (plain BatchNorm + ReLU between two convolutions)
@@ -699,7 +735,9 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
                             const int* tap_woff, int tile, int smallc, const void* zeros, const void* bn_y,
-                            const float* bn_consts, const void* bn_bits, void* stream) {
+                            const float* bn_consts, const void* bn_bits, int act, void* out2, const void* act_src,
+                            void* stream) {
+    if (act < 0 || act > 2 || (act == 1 && (out2 == nullptr || bias == nullptr)) || (act == 2 && act_src == nullptr)) return -1;
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
     // packed rows: `smallc` is the row width tw; pixels are C (4 or 8) elements apart; B rows cover whole K-steps
@@ -719,6 +757,9 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.bn_consts = bn_consts;
     a.bn_bits = static_cast<const uint8_t*>(bn_bits);
     a.stat_rows = bn_y != nullptr ? 3 : 2;
+    a.act = act;
+    a.out2 = static_cast<bf16*>(out2);
+    a.act_src = static_cast<const bf16*>(act_src);
     if (bn_y != nullptr && (smallc || tile < 10)) return -1;  // only the ring kernels have this epilogue
     a.M = M; a.N = N; a.ldb = ldb; a.ldo = ldo; a.C = C; a.T = T;
     a.Hin = Hin; a.Win = Win; a.istr = istr;

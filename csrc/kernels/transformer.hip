@@ -192,24 +192,12 @@ PDT_API int pdt_layernorm_bwd(const void* dy, const void* x, const float* gamma,
 // ------------------------------------------------------------------------------------------------
 // GELU (tanh form)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.f + tanhf(u));
-}
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    const float x2 = x * x;
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
-    const float t = tanhf(u);
-    const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
-    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
-}
-
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long nvec) {
     for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + v * 8);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(gelu_f(bf16_to_f32(xv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(pdt_gelu(bf16_to_f32(xv[e])));
         *reinterpret_cast<bf16x8*>(y + v * 8) = o;
     }
 }
@@ -221,7 +209,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + v * 8);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(bf16_to_f32(gv[e]) * gelu_grad_f(bf16_to_f32(xv[e])));
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(bf16_to_f32(gv[e]) * pdt_gelu_grad(bf16_to_f32(xv[e])));
         *reinterpret_cast<bf16x8*>(dx + v * 8) = o;
     }
 }

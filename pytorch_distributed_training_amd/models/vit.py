@@ -25,8 +25,7 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x, residual, link=None):
-        h = ops.linear(x, self.fc1.weight, self.fc1.bias, activation="gelu")
-        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, link=link)  # both added in the epilogue
+        return ops.gelu_mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual=residual, link=link)
 
 
 class SelfAttention(nn.Module):

@@ -93,6 +93,14 @@ def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None
     return _ref.linear(x, weight, bias, activation, residual)
 
 
+def gelu_mlp(x, w1, b1, w2, b2, residual=None, link=None):
+    """gelu(x W1^T + b1) W2^T + b2 (+ residual): the transformer feed-forward block.  On GPU every element-wise
+    step (bias, GELU, residual, GELU's derivative, bias gradients) runs inside a GEMM epilogue."""
+    if x.is_cuda and b1 is not None and b2 is not None and not (w1.shape[0] % 64 or w1.shape[1] % 64 or w2.shape[0] % 64):
+        return _hip().gelu_mlp(x, w1, b1, w2, b2, residual, link)
+    return linear(linear(x, w1, b1, activation="gelu"), w2, b2, residual=residual, link=link)
+
+
 def softmax_cross_entropy(logits, labels):
     if logits.is_cuda:
         return _hip().softmax_cross_entropy(logits, labels)

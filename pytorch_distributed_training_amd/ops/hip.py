@@ -41,7 +41,7 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
@@ -382,9 +382,11 @@ def _pick_tile(m: int, n: int) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None) -> None:
+                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None, gelu_out=None, gelu_of=None) -> None:
     """``bn_stat = (y, consts, bits_or_None)``: also accumulate BatchNorm-backward sums of the result into ``stats``
-    ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`)."""
+    ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`).
+    ``gelu_out``: tensor (layout of ``out``) that receives gelu(result) while ``out`` keeps the pre-activation.
+    ``gelu_of``: pre-activation tensor (layout of ``out``); the result is multiplied by gelu'(gelu_of)."""
     bn_y = bn_consts = bn_bits = None
     if bn_stat is not None:
         bn_y, bn_consts, bn_bits = bn_stat
@@ -395,7 +397,8 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc),
-                     _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _stream()),
+                     _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits),
+                     1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _stream()),
         "gather_gemm",
     )
 
@@ -979,6 +982,107 @@ class _Linear(torch.autograd.Function):
             ctx.link.grad = gp.view(ctx.res_shape)  # npad == n here: gp is the contiguous bf16 gradient
             return dx, dw, db, None, None
         return dx, dw, db, (g if has_res else None), None
+
+
+class _GeluMLP(torch.autograd.Function):
+    """out = gelu(x W1^T + b1) W2^T + b2 (+ residual) as four GEMM launches forward+backward-data and two
+    weight-gradient launches, with every element-wise step inside a GEMM epilogue: the first GEMM stores the
+    pre-activation and its GELU, the second adds bias and residual, the data-gradient GEMM of the second layer
+    multiplies by gelu' on the way out, and the weight-gradient kernels sum the bias gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual=None, link=None):
+        hd, k = w1.shape
+        n = w2.shape[0]
+        if k % 64 or hd % 64 or n % 64 or w2.shape[1] != hd:
+            raise ValueError("fused MLP needs feature sizes that are multiples of 64")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, k)
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        h = torch.empty((M, hd), dtype=torch.bfloat16, device=x.device)
+        g = torch.empty_like(h)
+        out = torch.empty((M, n), dtype=torch.bfloat16, device=x.device)
+        _check_size(h)
+        one = [(0, 0, 0)]
+        _launch_gather_gemm(x2, SHADOWS.fwd(w1), h, None, b1.detach(), M, hd, k, hd, k, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0,
+                            gelu_out=g)
+        addend = None
+        if residual is not None:
+            if residual.numel() != M * n:
+                raise ValueError("residual must have the output's shape")
+            addend = residual.reshape(M, n)
+            if addend.dtype != torch.bfloat16:
+                addend = addend.to(torch.bfloat16)
+            if not addend.is_contiguous():
+                addend = addend.contiguous()
+        _launch_gather_gemm(g, SHADOWS.fwd(w2), out, None, b2.detach(), M, n, hd, n, hd, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0,
+                            addend=addend)
+        ctx.save_for_backward(x2, h, g, w1, w2)
+        ctx.biases = (b1, b2)
+        ctx.meta = (lead, M, k, hd, n, residual is not None)
+        ctx.link = link if (link is not None and residual is not None and link.armed) else None
+        ctx.res_shape = residual.shape if residual is not None else None
+        return out.reshape(*lead, n)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, h, g, w1, w2 = ctx.saved_tensors
+        b1, b2 = ctx.biases
+        lead, M, k, hd, n, has_res = ctx.meta
+        dev = gout.device
+        gp = gout.reshape(M, n)
+        if gp.dtype != torch.bfloat16:
+            gp = gp.to(torch.bfloat16)
+        if not gp.is_contiguous():
+            gp = gp.contiguous()
+        one = [(0, 0, 0)]
+
+        def weight_and_bias_grads(dy, inp, w, b, wi, bi, nn_, kk_):
+            """Weight gradient (and the bias gradient, by the same kernel when it can) into sinks or fresh buffers."""
+            dw = db = None
+            want_b = ctx.needs_input_grad[bi]
+            bsink = _grad_sink(b, (nn_,)) if want_b else None
+            bbuf = (bsink if bsink is not None else torch.zeros(nn_, dtype=torch.float32, device=dev)) if want_b else None
+            done = False
+            if ctx.needs_input_grad[wi]:
+                sink = _grad_sink(w, (nn_, kk_))
+                dw = sink if sink is not None else torch.zeros((nn_, kk_), dtype=torch.float32, device=dev)
+                done = _launch_wgrad(dy, inp, dw, M, nn_, nn_, kk_, one, kk_, 1, 1, 1, 1, 1, dbias=bbuf)
+                if sink is not None:
+                    dw = None
+            if want_b:
+                if not done:
+                    _check(_colsum(dy.data_ptr(), bbuf.data_ptr(), M, nn_, nn_, _stream()), "colsum")
+                db = None if bsink is not None else bbuf
+            return dw, db
+
+        # second layer: dh = (gout W2) * gelu'(h), dW2 = gout^T g, db2 = colsum(gout)
+        w2t, _ = SHADOWS.dgrad(w2, 1)  # [hd][n]
+        dh = torch.empty_like(h)
+        _launch_gather_gemm(gp, w2t, dh, None, None, M, hd, n, hd, n, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, gelu_of=h)
+        dw2, db2 = weight_and_bias_grads(gp, g, w2, b2, 3, 4, n, hd)
+        # first layer
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w1t, _ = SHADOWS.dgrad(w1, 1)  # [k][hd]
+            dx = torch.empty((M, k), dtype=torch.bfloat16, device=dev)
+            _launch_gather_gemm(dh, w1t, dx, None, None, M, k, hd, k, hd, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+            dx = dx.reshape(*lead, k)
+        dw1, db1 = weight_and_bias_grads(dh, x2, w1, b1, 1, 2, hd, k)
+        dres = None
+        if ctx.link is not None:
+            ctx.link.grad = gp.view(ctx.res_shape)
+        elif has_res:
+            dres = gout
+        return dx, dw1, db1, dw2, db2, dres, None
+
+
+def gelu_mlp(x, w1, b1, w2, b2, residual=None, link=None):
+    return _GeluMLP.apply(x, w1, b1, w2, b2, residual, link)
 
 
 def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None, link=None):

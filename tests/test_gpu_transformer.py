@@ -218,3 +218,38 @@ def test_skip_link_is_bypassed_when_the_layernorm_input_needs_no_gradient(ht):
     y = ops.linear(ops.layer_norm(x, ln.weight, ln.bias, ln.eps, link=link), lin.weight, lin.bias, residual=x, link=link)
     y.float().sum().backward()
     assert not link.armed and link.grad is None and lin.weight.grad is not None
+
+
+@pytest.mark.parametrize("rows,d,hd,res", [(197 * 16, 768, 3072, True), (4096, 1024, 4096, True), (200, 256, 512, False), (1000, 128, 512, True)])
+def test_fused_gelu_mlp_matches_the_composition(ht, rows, d, hd, res):
+    """Large shapes take the ring GEMM kernels (GELU, its derivative, bias gradients in the epilogues), small
+    ones the register-staged kernel; both are compared with the fp32 PyTorch composition."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.ops import reference as ref
+
+    torch.manual_seed(11)
+    dev = torch.device("cuda", 0)
+    fc1, fc2 = nn.Linear(d, hd).to(dev), nn.Linear(hd, d).to(dev)
+    x0 = torch.randn(rows, d, device=dev).to(torch.bfloat16)
+    r0 = torch.randn(rows, d, device=dev).to(torch.bfloat16)
+    g = torch.randn(rows, d, device=dev).to(torch.bfloat16)
+
+    xa, ra = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    ya = ops.gelu_mlp(xa, fc1.weight, fc1.bias, fc2.weight, fc2.bias, residual=ra if res else None)
+    ya.backward(g)
+    got = [xa.grad.float(), fc1.weight.grad.clone(), fc1.bias.grad.clone(), fc2.weight.grad.clone(), fc2.bias.grad.clone()]
+    if res:
+        assert _rel(ra.grad, g) < 1e-6
+    for p_ in list(fc1.parameters()) + list(fc2.parameters()):
+        p_.grad = None
+
+    xb, rb = x0.float().requires_grad_(True), r0.float()
+    w1 = fc1.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    w2 = fc2.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    b1 = fc1.bias.detach().clone().requires_grad_(True)
+    b2 = fc2.bias.detach().clone().requires_grad_(True)
+    yb = ref.linear(ref.linear(xb, w1, b1, activation="gelu"), w2, b2, residual=rb if res else None)
+    yb.backward(g.float())
+    assert _rel(ya, yb) < 1e-2
+    for a, b in zip(got, [xb.grad, w1.grad, b1.grad, w2.grad, b2.grad]):
+        assert _rel(a, b) < 1.5e-2
