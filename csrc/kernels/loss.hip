@@ -122,6 +122,92 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
     }
 }
 
+// ---- long bf16 rows, forward and gradient in one pass: a 512-thread workgroup holds its row in registers
+// (NV 16-byte vectors per thread), so the logits are read from memory once and the gradient
+// (softmax - onehot) / rows is written straight away; the backward pass only has to scale it by the
+// incoming gradient, which for a loss that is the root of the graph is 1.
+template <int NV>
+__global__ __launch_bounds__(512) void ce_fused_row_kernel(const bf16* __restrict__ logits, const long long* __restrict__ labels,
+                                                          float* __restrict__ row_loss, bf16* __restrict__ dlogits,
+                                                          int rows, int classes, long long ld_row, long long ld_drow,
+                                                          int pad_to) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const bf16* x = logits + row * ld_row;
+    const int nvec = (classes + 7) >> 3;  // vectors that hold at least one class (ld_row covers them)
+    bf16x8 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * 512;
+        if (vi < nvec) v[i] = *reinterpret_cast<const bf16x8*>(x + vi * 8);
+    }
+    const long long y = labels[row];
+    const bool valid = y >= 0 && y < classes;
+    float m = CE_NEG, xy = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * 512;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = vi * 8 + e;
+                const float f = bf16_to_f32(v[i][e]);
+                if (c < classes) m = fmaxf(m, f);
+                if (c == y) xy = f;
+            }
+        }
+    }
+    m = block_max(m, red);
+    const float ml2 = m * 1.4426950408889634f;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * 512;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (vi * 8 + e < classes) s += __builtin_amdgcn_exp2f(bf16_to_f32(v[i][e]) * 1.4426950408889634f - ml2);
+        }
+    }
+    s = block_sum(s, red);
+    xy = block_sum(xy, red);  // one thread holds the label's logit, the others 0
+    const float l = m + __logf(s);
+    if (threadIdx.x == 0) row_loss[row] = valid ? l - xy : 0.f;
+    if (dlogits == nullptr) return;
+    const float g = valid ? 1.f / rows : 0.f;
+    const float ll2 = l * 1.4426950408889634f;
+    bf16* d = dlogits + row * ld_drow;
+    const int pvec = pad_to >> 3;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * 512;
+        if (vi < pvec) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = vi * 8 + e;
+                float r = 0.f;
+                if (vi < nvec && c < classes)
+                    r = (__builtin_amdgcn_exp2f(bf16_to_f32(v[i][e]) * 1.4426950408889634f - ll2) - (c == y ? 1.f : 0.f)) * g;
+                o[e] = f32_to_bf16(r);
+            }
+            *reinterpret_cast<bf16x8*>(d + vi * 8) = o;
+        }
+    }
+}
+
+// x *= g[0] unless g[0] == 1 (the gradient of a loss that is the root of the graph)
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(bf16* __restrict__ x, const float* __restrict__ g, long long nvec) {
+    const float gv = g[0];
+    if (gv == 1.f) return;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nvec; i += gridDim.x * 256ll) {
+        bf16x8 v = *reinterpret_cast<bf16x8*>(x + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * gv);
+        *reinterpret_cast<bf16x8*>(x + i * 8) = v;
+    }
+}
+
 // deterministic mean of a float vector -> out[0]  (single workgroup)
 __global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
                                                    float scale) {
@@ -159,5 +245,37 @@ PDT_API int pdt_softmax_ce_bwd(const void* logits, const long long* labels, cons
     const dim3 g(rows < 8192 ? rows : 8192), b(256);
     if (dtype == 1) hipLaunchKernelGGL(ce_bwd_kernel<bf16>, g, b, 0, s, static_cast<const bf16*>(logits), labels, lse, gout, static_cast<bf16*>(dlogits), rows, classes, ld_row, ld_drow, pad_to);
     else hipLaunchKernelGGL(ce_bwd_kernel<float>, g, b, 0, s, static_cast<const float*>(logits), labels, lse, gout, static_cast<float*>(dlogits), rows, classes, ld_row, ld_drow, pad_to);
+    return pdt_launch_status();
+}
+
+// Forward and gradient in one pass for bf16 logits with long rows (see ce_fused_row_kernel).  dlogits may be
+// nullptr (no gradient wanted); it has row stride ld_drow and columns [classes, pad_to) are written as zeros.
+// Needs classes > 1024, ld_row, ld_drow and pad_to multiples of 8, ld_row >= classes rounded up to 8, and at
+// most 65536 classes.  The gradient is for an incoming gradient of 1: scale with pdt_scale_by_scalar.
+PDT_API int pdt_softmax_ce_fused(const void* logits, const long long* labels, float* row_loss, float* loss, void* dlogits,
+                                 int rows, int classes, long long ld_row, long long ld_drow, int pad_to, void* stream) {
+    const int c8 = (classes + 7) / 8 * 8;
+    if (rows <= 0 || classes <= 1024 || classes > 65536 || (ld_row % 8) != 0 || ld_row < c8) return -1;
+    if (dlogits != nullptr && ((ld_drow % 8) != 0 || (pad_to % 8) != 0 || pad_to < c8 || ld_drow < pad_to || pad_to > 65536)) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int need = (((dlogits != nullptr ? pad_to : c8) >> 3) + 511) / 512;
+    const bf16* x = static_cast<const bf16*>(logits);
+    bf16* d = static_cast<bf16*>(dlogits);
+#define PDT_CE(NV) hipLaunchKernelGGL(ce_fused_row_kernel<NV>, dim3(rows), dim3(512), 0, s, x, labels, row_loss, d, rows, classes, ld_row, ld_drow, pad_to)
+    if (need <= 4) PDT_CE(4);
+    else if (need <= 8) PDT_CE(8);
+    else if (need <= 13) PDT_CE(13);
+    else PDT_CE(16);
+#undef PDT_CE
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, row_loss, loss, static_cast<long long>(rows), 1.f / rows);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_scale_by_scalar(void* x, const float* g, long long numel, void* stream) {
+    if (numel <= 0 || (numel % 8) != 0) return -1;
+    long long blocks = (numel / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<bf16*>(x), g, numel / 8);
     return pdt_launch_status();
 }

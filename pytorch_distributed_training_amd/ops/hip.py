@@ -55,6 +55,8 @@ _avgpool_fwd = _sig("pdt_avgpool_fwd", [_vp, _vp, _i, _i, _i, _vp])
 _avgpool_bwd = _sig("pdt_avgpool_bwd", [_vp, _vp, _i, _i, _i, _vp])
 _ce_fwd = _sig("pdt_softmax_ce_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp])
 _ce_bwd = _sig("pdt_softmax_ce_bwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _vp])
+_ce_fused = _sig("pdt_softmax_ce_fused", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _vp])
+_scale_by_scalar = _sig("pdt_scale_by_scalar", [_vp, _vp, _ll, _vp])
 _nchw_to_nhwc = _sig("pdt_nchw_to_nhwc_bf16", [_vp, _vp, _i, _i, _i, _i, _i, _vp])
 _pad_pixels = _sig("pdt_pad_pixels", [_vp, _vp] + [_i] * 8 + [_vp])
 _cast_pad = _sig("pdt_cast_pad_f32_bf16", [_vp, _vp, _ll, _i, _i, _vp])
@@ -1112,8 +1114,22 @@ class _SoftmaxCE(torch.autograd.Function):
             raise ValueError("labels and logits disagree on the number of rows")
         dev = logits.device
         row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
-        lse = torch.empty(rows, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ld = logits.stride(0)
+        ctx.fused = None
+        if logits.dtype == torch.bfloat16 and 1024 < classes <= 65536 and ld % 8 == 0 and ld >= _round_up(classes, 8):
+            # language-model vocabularies: the gradient is produced by the forward pass, which holds each row in
+            # registers and so reads the logits once; the backward pass only scales it by the incoming gradient
+            c8 = _round_up(classes, 8)
+            pad_to = ld if ld - classes < 64 else c8
+            dbuf = None
+            if ctx.needs_input_grad[0]:
+                dbuf = torch.empty((rows, pad_to), dtype=torch.bfloat16, device=dev)
+            _check(_ce_fused(logits.data_ptr(), labels.data_ptr(), row_loss.data_ptr(), loss.data_ptr(), _ptr(dbuf), rows,
+                             classes, ld, pad_to, pad_to, _stream()), "softmax_ce_fused")
+            ctx.fused = [dbuf, classes, pad_to]
+            return loss.reshape(())
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
         dt = 1 if logits.dtype == torch.bfloat16 else 0
         _check(_ce_fwd(logits.data_ptr(), labels.data_ptr(), row_loss.data_ptr(), lse.data_ptr(), loss.data_ptr(), rows,
                        classes, logits.stride(0), dt, _stream()), "softmax_ce_fwd")
@@ -1122,6 +1138,17 @@ class _SoftmaxCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fused is not None:
+            dbuf, classes, pad_to = ctx.fused
+            if dbuf is None:
+                raise RuntimeError("the fused cross-entropy gradient was already handed out (backward ran twice)")
+            ctx.fused[0] = None
+            g1 = g.reshape(1).to(torch.float32).contiguous()
+            _check(_scale_by_scalar(dbuf.data_ptr(), g1.data_ptr(), dbuf.numel(), _stream()), "scale_by_scalar")
+            if pad_to != classes:
+                _PADDED_GRADS[dbuf.data_ptr()] = pad_to
+                return dbuf[:, :classes], None
+            return dbuf, None
         logits, labels, lse = ctx.saved_tensors
         rows, classes = logits.shape
         ld = logits.stride(0)

@@ -272,6 +272,29 @@ def test_softmax_cross_entropy(hip, rows, classes, dtype):
     assert _rel_err(logits.grad, lr.grad) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
 
 
+@pytest.mark.parametrize("rows,classes,ld,scale", [(96, 50257, 50304, 1.0), (96, 50257, 50304, 2.0), (64, 32000, 32000, 1.0), (40, 2048, 2048, 0.5), (16, 65536, 65536, 1.0)])
+def test_one_pass_cross_entropy_for_long_rows(hip, rows, classes, ld, scale):
+    """bf16 rows of more than 1024 classes with an 8-aligned stride: loss and gradient from one kernel that holds
+    the row in registers; the stride's padding columns hold garbage that must be ignored and get zero gradient."""
+    torch.manual_seed(6)
+    dev = _dev()
+    buf = (3 * torch.randn(rows, ld, device=dev)).to(torch.bfloat16)
+    base = buf.clone().requires_grad_(True)
+    logits = base[:, :classes]
+    labels = torch.randint(0, classes, (rows,), device=dev)
+    labels[0] = classes - 1
+    loss = hip.softmax_cross_entropy(logits, labels)
+    lr = buf[:, :classes].float().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels)
+    assert abs(float(loss) - float(ref)) < 2e-3 * max(1.0, abs(float(ref)))
+    (scale * loss).backward()
+    (scale * ref).backward()
+    assert _rel_err(base.grad[:, :classes], lr.grad) < 1e-2
+    assert float(base.grad[:, classes:].abs().sum()) == 0.0
+    with torch.no_grad():  # inference: no gradient buffer is produced
+        assert abs(float(hip.softmax_cross_entropy(buf[:, :classes], labels)) - float(ref)) < 2e-3 * max(1.0, abs(float(ref)))
+
+
 @pytest.mark.parametrize("mode", ["adam", "adamw", "sgd"])
 def test_multi_tensor_optimizer_matches_cpu_definition(mode):
     from pytorch_distributed_training_amd.optim import FusedOptimizer
