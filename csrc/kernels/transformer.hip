@@ -61,19 +61,21 @@ PDT_API int pdt_layernorm_fwd(const void* x, const float* gamma, const float* be
 
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ addend);  dgamma += dy*xhat;  dbeta += dy
 // Each wave walks rows row0, row0 + stride, ...; a lane always owns the same columns, so it keeps gamma and its
-// dgamma/dbeta partial sums in registers (MAXV vectors of 8 columns), combined per workgroup in LDS and added
-// to the zero-initialised fp32 outputs with one atomic per column.  A row's dy and x stay in registers between
+// dgamma/dbeta partial sums in registers (MAXV vectors of 8 columns), combined per workgroup in LDS and
+// written to the workgroup's row of `partial` ([workgroups][2][D]); layernorm_param_grad_kernel folds those
+// rows into dgamma / dbeta.  (Global atomics on the 2 D result addresses from every workgroup cost more
+// than the whole streaming pass.)  A row's dy and x stay in registers between
 // the reduction and the output pass (rows of up to 2048 columns), so each is read from memory once.
 // `addend` (optional) is a second gradient of the same input - the skip connection around the normalised
 // branch - added here instead of by a separate element-wise pass.
-template <int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+template <int MAXV, int LN_BWD_WAVES>
+__global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const bf16* __restrict__ addend,
-                                                           bf16* __restrict__ dx, float* dgamma, float* dbeta, int rows, int D) {
+                                                           bf16* __restrict__ dx, float* __restrict__ partial, int rows, int D) {
     constexpr bool KEEP = MAXV <= 4;
     constexpr int NK = KEEP ? MAXV : 1;
-    extern __shared__ float sred[];  // [2][D]
+    __shared__ float sred[2 * MAXV * 8 * 64];  // [dgamma | dbeta][vector i][element e][lane]: conflict-free per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
     float ag[MAXV][8], ab[MAXV][8], gm[NK][8];
@@ -89,9 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
             for (int e = 0; e < 8; ++e) gm[i][e] = v < nv ? gamma[v * 8 + e] : 0.f;
         }
     }
-    for (int idx = threadIdx.x; idx < 2 * D; idx += 256) sred[idx] = 0.f;
-    __syncthreads();
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * LN_BWD_WAVES + wave; row < rows; row += gridDim.x * LN_BWD_WAVES) {
         const bf16* dyr = dy + static_cast<size_t>(row) * D;
         const bf16* xr = x + static_cast<size_t>(row) * D;
         const bf16* ar = addend != nullptr ? addend + static_cast<size_t>(row) * D : nullptr;
@@ -150,42 +150,87 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
             }
         }
     }
+    // The waves add their register sums into LDS one after the other (LDS float atomics are far slower than
+    // this: they dominated the kernel's run time).
+    for (int w = 0; w < LN_BWD_WAVES; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int v = lane + 64 * i;
-        if (v < nv) {
+            for (int i = 0; i < MAXV; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(&sred[v * 8 + e], ag[i][e]);
-                atomicAdd(&sred[D + v * 8 + e], ab[i][e]);
-            }
+                for (int e = 0; e < 8; ++e) {
+                    const int a = (i * 8 + e) * 64 + lane, b = (MAXV * 8 + i * 8 + e) * 64 + lane;
+                    sred[a] = w == 0 ? ag[i][e] : sred[a] + ag[i][e];
+                    sred[b] = w == 0 ? ab[i][e] : sred[b] + ab[i][e];
+                }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < D; idx += 256) {
-        __hip_atomic_fetch_add(dgamma + idx, sred[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(dbeta + idx, sred[D + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float* out = partial + static_cast<size_t>(blockIdx.x) * 2 * D;
+    for (int idx = threadIdx.x; idx < 2 * MAXV * 8 * 64; idx += LN_BWD_WAVES * 64) {
+        const int ln = idx & 63, j = idx >> 6;
+        const int which = j / (MAXV * 8), r = j - which * (MAXV * 8);
+        const int v = ln + 64 * (r >> 3);
+        if (v < nv) out[which * D + v * 8 + (r & 7)] = sred[idx];
     }
 }
 
-// dgamma / dbeta must be zero-initialised (or hold a running sum).  addend: optional bf16 [rows, D] added to dx.
+// dgamma[c] += sum_b partial[b][c], dbeta[c] += sum_b partial[b][D + c]: one workgroup per 64 of the 2 D columns,
+// its four waves take every fourth row of `partial`.
+__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float* __restrict__ partial, int nparts, int D,
+                                                                  float* dgamma, float* dbeta) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;  // column of the [2 D] row
+    float t = 0.f;
+    if (c < 2 * D) {
+#pragma unroll 8
+        for (int b = wave; b < nparts; b += 4) t += partial[static_cast<size_t>(b) * 2 * D + c];
+    }
+    red[wave][lane] = t;
+    __syncthreads();
+    if (wave == 0 && c < 2 * D) {
+        t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (c < D) dgamma[c] += t;
+        else dbeta[c - D] += t;
+    }
+}
+
+// Rows of up to 1024 columns: 8 waves per workgroup, one workgroup per CU (2048 waves; more waves or more
+// workgroups only add reduction work).  Longer rows need more registers per lane: 4 waves per workgroup.
+static void ln_bwd_config(int D, int* waves, int* cap) {
+    const bool small = D <= 1024;
+    *waves = small ? 8 : 4;
+    *cap = small ? 256 : 512;
+}
+
+// Workgroups the backward kernel is launched with = rows of `partial` the caller must provide.
+PDT_API int pdt_layernorm_bwd_parts(int rows, int D) {
+    int waves, cap;
+    ln_bwd_config(D, &waves, &cap);
+    const int g = pdt_cdiv(rows, waves);
+    return g < cap ? g : cap;
+}
+
+// dgamma / dbeta are added to (zero-initialise them, or pass a running sum); they must not be written by anything
+// else while this runs.  addend: optional bf16 [rows, D] added to dx.  partial: fp32 [pdt_layernorm_bwd_parts(rows, D)][2 D].
 PDT_API int pdt_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                              void* dx, float* dgamma, float* dbeta, int rows, int D, const void* addend, void* stream) {
-    if (rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * 64 * 8) return -1;
+                              void* dx, float* dgamma, float* dbeta, int rows, int D, const void* addend, float* partial,
+                              void* stream) {
+    if (rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * 64 * 8 || partial == nullptr) return -1;
     const int nv = D / 8, maxv = (nv + 63) / 64;
-    int grid = pdt_cdiv(rows, 4);
-    const int cap = maxv <= 2 ? 1280 : 768;  // workgroups that are resident together at this register footprint
-    if (grid > cap) grid = cap;
-    const size_t lds = 2ull * D * sizeof(float);
+    const int grid = pdt_layernorm_bwd_parts(rows, D);
+    int waves, cap;
+    ln_bwd_config(D, &waves, &cap);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16 *pdy = static_cast<const bf16*>(dy), *px = static_cast<const bf16*>(x), *pa = static_cast<const bf16*>(addend);
     bf16* pdx = static_cast<bf16*>(dx);
-#define PDT_LN(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), lds, s, pdy, px, gamma, mean, rstd, pa, pdx, dgamma, dbeta, rows, D)
-    if (maxv <= 1) PDT_LN(1);
-    else if (maxv <= 2) PDT_LN(2);
-    else if (maxv <= 4) PDT_LN(4);
-    else PDT_LN(8);
+#define PDT_LN(V, W) hipLaunchKernelGGL((layernorm_bwd_kernel<V, W>), dim3(grid), dim3(W * 64), 0, s, pdy, px, gamma, mean, rstd, pa, pdx, partial, rows, D)
+    if (maxv <= 1) PDT_LN(1, 8);
+    else if (maxv <= 2) PDT_LN(2, 8);
+    else if (maxv <= 4) PDT_LN(4, 4);
+    else PDT_LN(8, 4);
 #undef PDT_LN
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(pdt_cdiv(2 * D, 64)), dim3(256), 0, s, partial, grid, D, dgamma, dbeta);
     return pdt_launch_status();
 }
 

@@ -26,7 +26,8 @@ def _sig(name, argtypes):
 
 
 _ln_fwd = _sig("pdt_layernorm_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp])
-_ln_bwd = _sig("pdt_layernorm_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp])
+_ln_bwd = _sig("pdt_layernorm_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp])
+_ln_bwd_parts = _sig("pdt_layernorm_bwd_parts", [_i, _i])
 _gelu_fwd = _sig("pdt_gelu_fwd", [_vp, _vp, _ll, _vp])
 _gelu_bwd = _sig("pdt_gelu_bwd", [_vp, _vp, _vp, _ll, _vp])
 _bias_res = _sig("pdt_bias_residual", [_vp, _vp, _vp, _vp, _ll, _i, _vp])
@@ -96,8 +97,9 @@ class _LayerNorm(torch.autograd.Function):
             ctx.link.grad = None
             if addend.shape != x.shape or addend.dtype != torch.bfloat16 or not addend.is_contiguous():
                 raise RuntimeError("the linked skip gradient does not match the LayerNorm input")
+        partial = torch.empty((_ln_bwd_parts(rows, d), 2 * d), dtype=torch.float32, device=x.device)
         _check(_ln_bwd(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                       dg.data_ptr(), db.data_ptr(), rows, d, _ptr(addend), _stream()), "layernorm_bwd")
+                       dg.data_ptr(), db.data_ptr(), rows, d, _ptr(addend), partial.data_ptr(), _stream()), "layernorm_bwd")
         if sw is not None:
             return dx, None, None, None, None
         return dx, dg, db, None, None
