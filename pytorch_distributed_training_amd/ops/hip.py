@@ -430,6 +430,37 @@ def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int]
     return max(1, min(max(min(want, cap), floor), M // 256))
 
 
+# LDS-DMA ring kernels for weight gradients with N >= 128 and >= 128 columns: (tile id, BN, BC, relative MFMA rate
+# of the main loop measured on large problems)
+_WGRAD_RING_TILES = ((16, 256, 256, 1.0), (11, 256, 128, 0.87), (12, 128, 256, 0.78), (10, 128, 128, 0.6))
+# the fp32-atomic epilogue of one workgroup costs about as much as this many 64-pixel K-steps of its main loop
+_WGRAD_EPILOGUE_KSTEPS = 25
+_wgrad_choice_cache: Dict[Tuple[int, int, int], int] = {}
+
+
+def _wgrad_ring_choice(M: int, N: int, kc: int) -> int:
+    """Tile with the smallest modelled run time: rounds of workgroups x (K-steps + epilogue) x tile area / rate.
+    The model reproduces the measured ranking on the transformer and ResNet shapes (bench/gemm_bench.py
+    --wgrad-only under PDT_WGRAD_RING=10/11/12/16): large tiles win while their tile count still divides the
+    CUs well, small ones when few K-steps are left per workgroup and the epilogue dominates."""
+    key = (M, N, kc)
+    hit = _wgrad_choice_cache.get(key)
+    if hit is not None:
+        return hit
+    cus = WGRAD_RING_TARGET_BLOCKS or _num_cus()
+    best, best_cost = 11, None
+    for tile, bn, bc, rate in _WGRAD_RING_TILES:
+        tiles = math.ceil(N / bn) * math.ceil(kc / bc)
+        splits = _wgrad_splits(M, N, kc, 1, bn, bc, cus)
+        rounds = math.ceil(tiles * splits / cus)
+        ksteps = math.ceil(math.ceil(M / splits) / 64)
+        cost = rounds * (ksteps + _WGRAD_EPILOGUE_KSTEPS) * bn * bc / rate
+        if best_cost is None or cost < best_cost:
+            best, best_cost = tile, cost
+    _wgrad_choice_cache[key] = best
+    return best
+
+
 def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=0, dbias=None) -> bool:
     """Launch the weight-gradient kernel.  ``dbias``: fp32 [N] buffer that should also receive the column sums
     of ``dy`` (the bias gradient); returns True when the chosen kernel did that, False when the caller still
@@ -441,11 +472,7 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
     elif WGRAD_RING and smallc:
         tile = 15
     elif WGRAD_RING and N >= 128 and kc >= 128:
-        # LDS-DMA ring kernel, one workgroup of 8 waves per CU; the 256-wide side goes to the larger dimension
-        if N >= 256 and kc >= 256 and N * kc >= 1536 * 1024 and 2 * kc >= N:
-            tile = 16  # 256 x 256: a third less operand traffic per FLOP; pays for the large transformer weights
-        else:
-            tile = 11 if N >= 256 and N >= kc else (12 if kc >= 256 else 10)
+        tile = _wgrad_ring_choice(M, N, kc)
     elif WGRAD_RING and N < 128 and kc >= 192:
         tile = 13  # 64 x 256: all output channels of a narrow layer, several taps per tile
     elif WGRAD_RING and N >= 256 and kc < 128:
