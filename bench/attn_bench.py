@@ -1,0 +1,52 @@
+"""Fused attention kernels alone: forward and backward time on the GPT-2 medium and ViT-B/16 shapes.
+
+    python bench/attn_bench.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+SHAPES = [("gpt2-medium b16", 16, 1024, 16, True), ("vit-b/16 b256", 256, 197, 12, False), ("long 4k", 4, 4096, 16, True)]
+
+
+def _time(run, iters=20):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def main():
+    from pytorch_distributed_training_amd.ops import hip_transformer as ht
+
+    dev = torch.device("cuda", 0)
+    print(f"{'shape':<18}{'fwd us':>9}{'TF/s':>7}{'bwd us':>9}{'TF/s':>7}   (FLOPs: 4 B H S^2 64 forward, 2.5x backward; halved when causal)")
+    for name, b, s, h, causal in SHAPES:
+        qkv = torch.randn(b, s, 3 * h * 64, device=dev).to(torch.bfloat16).requires_grad_(True)
+        g = torch.randn(b, s, h * 64, device=dev).to(torch.bfloat16)
+        flops = 4.0 * b * h * s * s * 64 * (0.5 if causal else 1.0)
+        with torch.no_grad():
+            tf = _time(lambda: ht.attention_qkv(qkv, h, causal))
+        out = ht.attention_qkv(qkv, h, causal)
+
+        def bwd():
+            qkv.grad = None
+            out.backward(g, retain_graph=True)
+
+        tb = _time(bwd)
+        print(f"{name:<18}{tf * 1e6:9.1f}{flops / tf / 1e12:7.0f}{tb * 1e6:9.1f}{2.5 * flops / tb / 1e12:7.0f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@
 //
 // Not exercised by the reference (CNN only, /root/reference/src/main.py:49); serves ViT-B/16 and GPT-2.
 #include "common.h"
+#include <cstdlib>
 
 #define AT_D 64
 #define AT_T 64           // tile length along the streamed sequence
@@ -120,29 +121,42 @@ __device__ __forceinline__ float group_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// QF query fragments of 16 per wave: a workgroup owns 64 * QF queries.  With QF = 2 every K / V fragment read
+// from LDS feeds two MFMAs, and the barriers and the staging of a tile are amortised over twice the work.
+template <int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
     __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * 64;
-    const int qrow = q0 + wave * 16 + i;  // this lane's query
+    const int q0 = blockIdx.x * (64 * QF);
+    int qrow[QF];  // this lane's queries
+#pragma unroll
+    for (int f = 0; f < QF; ++f) qrow[f] = q0 + (wave * QF + f) * 16 + i;
     const size_t srow = static_cast<size_t>(3) * p.H * AT_D;  // elements between consecutive sequence positions
 
-    bf16x8 qf[2];
-    {
+    bf16x8 qf[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
         const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16* qp = p.qkv + qkv_off(p, b, min(qrow, p.S - 1), 0, h);
+        const bf16* qp = p.qkv + qkv_off(p, b, min(qrow[f], p.S - 1), 0, h);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = qrow < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
+        for (int ks = 0; ks < 2; ++ks) qf[f][ks] = qrow[f] < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
     }
-    f32x4 o[4];
+    f32x4 o[QF][4];
+    float m[QF], l[QF];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = AT_NEG, l = 0.f;
+    for (int f = 0; f < QF; ++f) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[f][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[f] = AT_NEG;
+        l[f] = 0.f;
+    }
 
-    const int kend = p.causal ? min(p.S, q0 + 64) : p.S;
+    const int kend = p.causal ? min(p.S, q0 + 64 * QF) : p.S;
+    // keys this wave needs under a causal mask: up to its own last query (wave-uniform); later tiles are skipped
+    const int wave_kend = p.causal ? min(p.S, q0 + (wave * QF + QF) * 16) : p.S;
     TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
     TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
     for (int k0 = 0; k0 < kend; k0 += AT_T) {
@@ -154,77 +168,92 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             rk = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 1, h), srow, p.S - k0 - AT_T, tid);
             rv = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 2, h), srow, p.S - k0 - AT_T, tid);
         }
-        f32x4 s[4];
+        if (k0 >= wave_kend) continue;  // every key of this tile is masked for every query of this wave
+        f32x4 s[QF][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t * 16, ks, lane), qf[ks], s[t], 0, 0, 0);
+            for (int f = 0; f < QF; ++f) s[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = frag_row(sK, t * 16, ks, lane);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][ks], s[f][t], 0, 0, 0);
+            }
         }
-        // Only the last key tile (keys beyond S) and, with a causal mask, the tile on the diagonal need
-        // per-element masking; the branch is uniform for the workgroup.
+        // Only the last key tile (keys beyond S) and, with a causal mask, the tiles that reach past the first
+        // query of the workgroup need per-element masking; the branch is uniform for the workgroup.
         const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T > q0);
-        float mx = AT_NEG;  // maximum of the raw scores; the softmax scale (> 0) is folded into the exponent's fma
-        if (masked) {
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float mx = AT_NEG;  // maximum of the raw scores; the softmax scale (> 0) is folded into the exponent's fma
+            if (masked) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = k0 + t * 16 + g * 4 + e;
+                        const bool ok = key < p.S && (!p.causal || key <= qrow[f]);
+                        s[f][t][e] = ok ? s[f][t][e] : AT_NEG;
+                        mx = fmaxf(mx, s[f][t][e]);
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][t][e]);
+            }
+            mx = group_max(mx) * p.scale_log2;
+            // The running maximum is raised only when a score exceeds it by more than 2^6: probabilities are then
+            // bounded by 64 instead of 1 (harmless in fp32 / bf16) and the rescaling of the output accumulators,
+            // which costs a round trip through the vector ALU, is skipped for most tiles.  Wave-uniform decision.
+            const bool raise = __any(mx > m[f] + 6.0f);
+            if (raise) {
+                const float mn = fmaxf(m[f], mx);
+                const float alpha = fast_exp2(m[f] - mn);
+                l[f] *= alpha;
+                m[f] = mn;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[f][dt][e] *= alpha;
+            }
+            float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + t * 16 + g * 4 + e;
-                    const bool ok = key < p.S && (!p.causal || key <= qrow);
-                    s[t][e] = ok ? s[t][e] : AT_NEG;
-                    mx = fmaxf(mx, s[t][e]);
+                    const float pv = fast_exp2(fmaf(s[f][t][e], p.scale_log2, -m[f]));  // masked scores are -1e30: 2^-huge = 0
+                    s[f][t][e] = pv;
+                    rs += pv;
                 }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][e]);
+            l[f] += group_sum(rs);
         }
-        mx = group_max(mx) * p.scale_log2;
-        // The running maximum is raised only when a score exceeds it by more than 2^6: probabilities are then
-        // bounded by 64 instead of 1 (harmless in fp32 / bf16) and the rescaling of the output accumulators,
-        // which costs a round trip through the vector ALU, is skipped for most tiles.  Wave-uniform decision.
-        const bool raise = __any(mx > m + 6.0f);
-        float rs = 0.f;
-        if (raise) {
-            const float mn = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - mn);
-            l *= alpha;
-            m = mn;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = fast_exp2(fmaf(s[t][e], p.scale_log2, -m));  // masked scores are -1e30: 2^-huge = 0
-                s[t][e] = pv;
-                rs += pv;
-            }
-        l += group_sum(rs);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int kp = 0; kp < 2; ++kp)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, kp * 32, dt * 16, lane),
-                                                                pack_pair(s[2 * kp], s[2 * kp + 1]), o[dt], 0, 0, 0);
+            for (int kp = 0; kp < 2; ++kp) {
+                const bf16x8 vf = frag_tr(sV, kp * 32, dt * 16, lane);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    o[f][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pack_pair(s[f][2 * kp], s[f][2 * kp + 1]), o[f][dt], 0, 0, 0);
+            }
     }
-    if (qrow < p.S) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-        bf16* op = p.out + ((static_cast<size_t>(b) * p.S + qrow) * p.H + h) * AT_D;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            bf16x4 v;
+    for (int f = 0; f < QF; ++f) {
+        if (qrow[f] < p.S) {
+            const float inv = l[f] > 0.f ? 1.f / l[f] : 0.f;
+            bf16* op = p.out + ((static_cast<size_t>(b) * p.S + qrow[f]) * p.H + h) * AT_D;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(o[dt][e] * inv);
-            *reinterpret_cast<bf16x4*>(op + dt * 16 + g * 4) = v;
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(o[f][dt][e] * inv);
+                *reinterpret_cast<bf16x4*>(op + dt * 16 + g * 4) = v;
+            }
+            if (g == 0)
+                p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow[f]] = (m[f] + log2f(fmaxf(l[f], 1e-30f))) * 0.6931471805599453f;
         }
-        if (g == 0) p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow] = (m + log2f(fmaxf(l, 1e-30f))) * 0.6931471805599453f;
     }
 }
 
@@ -481,7 +510,16 @@ PDT_API int pdt_attention_fwd(const void* qkv, void* out, float* lse, int B, int
     a.scale = scale;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.causal = causal;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    // 32 queries per wave pay for short non-causal sequences (ViT: +12 %); on long or causal ones the higher
+    // register footprint costs more occupancy than the halved LDS traffic gains (measured: bench/attn_bench.py)
+    static int qf_env = -1;
+    if (qf_env < 0) {
+        const char* e = getenv("PDT_ATTN_QF");
+        qf_env = e ? atoi(e) : 0;
+    }
+    const int qf = qf_env ? qf_env : ((S > 64 && S <= 512 && !causal) ? 2 : 1);
+    if (qf == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(pdt_cdiv(S, 128), B * H), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return pdt_launch_status();
 }
 

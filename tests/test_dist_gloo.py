@@ -101,3 +101,26 @@ def test_resnet18_trainer_two_ranks_checkpoint_rank0_only(tmp_path, free_port):
     r0 = torch.load(tmp_path / "res0.pt")
     r1 = torch.load(tmp_path / "res1.pt")
     assert r0["acc"] == r1["acc"]
+
+
+def test_bench_contract_two_ranks_under_torchrun(free_port):
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N --steps K --warmup W`), rehearsed with two gloo ranks on the CPU: rank 0 prints exactly one JSON line
+    whose value is the whole-job aggregate."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cpu", "--model", "resnet18", "--image-size", "32", "--batch-size", "4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and abs(rec["value"] - 8 / (rec["ms_per_step"] * 1e-3)) < 1e-2 * rec["value"]
