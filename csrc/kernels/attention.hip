@@ -125,8 +125,10 @@ __device__ __forceinline__ float group_sum(float v) {
 // from LDS feeds two MFMAs, and the barriers and the staging of a tile are amortised over twice the work.
 template <int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
-    __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_PITCH];
+    // K / V tiles are double-buffered in LDS: tile t + 1 is stored while tile t is being read, so one barrier
+    // per tile suffices and the LDS stores are a whole iteration ahead of their first read.
+    __shared__ __attribute__((aligned(16))) bf16 sKb[2][AT_T * AT_D];
+    __shared__ __attribute__((aligned(16))) bf16 sVb[2][AT_T * AT_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
@@ -144,14 +146,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[f][ks] = qrow[f] < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
     }
-    f32x4 o[QF][4];
-    float m[QF], l[QF];
+    // The softmax denominators are accumulated by the matrix unit as well: one more MFMA per 32 keys against a
+    // fragment of ones leaves sum_k P[k][query] in every row of `l` (all four registers of every lane group hold
+    // the query's total), which takes 16 additions and a cross-lane reduction per tile off the vector ALU.
+    f32x4 o[QF][4], l[QF];
+    float m[QF];
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = f32_to_bf16(1.f);
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[f][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         m[f] = AT_NEG;
-        l[f] = 0.f;
+        l[f] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     const int kend = p.causal ? min(p.S, q0 + 64 * QF) : p.S;
@@ -159,14 +167,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int wave_kend = p.causal ? min(p.S, q0 + (wave * QF + QF) * 16) : p.S;
     TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
     TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
-    for (int k0 = 0; k0 < kend; k0 += AT_T) {
-        __syncthreads();  // every wave is done with the previous tile
-        tile_store_swz(sK, rk, tid);
-        tile_store_pad(sV, rv, tid);
+    tile_store_swz(sKb[0], rk, tid);
+    tile_store_pad(sVb[0], rv, tid);
+    if (AT_T < kend) {
+        rk = tile_load(p.qkv + qkv_off(p, b, AT_T, 1, h), srow, p.S - AT_T, tid);
+        rv = tile_load(p.qkv + qkv_off(p, b, AT_T, 2, h), srow, p.S - AT_T, tid);
+    }
+    int buf = 0;
+    for (int k0 = 0; k0 < kend; k0 += AT_T, buf ^= 1) {
+        // tile k0 is complete in buffer `buf`, and every wave is done reading the other buffer (tile k0 - 64)
         __syncthreads();
-        if (k0 + AT_T < kend) {  // next tile: in flight during this tile's MFMAs
-            rk = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 1, h), srow, p.S - k0 - AT_T, tid);
-            rv = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 2, h), srow, p.S - k0 - AT_T, tid);
+        const bf16* sK = sKb[buf];
+        const bf16* sV = sVb[buf];
+        if (k0 + AT_T < kend) {  // registers hold tile k0 + 64 (loaded during the previous iteration): park it in LDS
+            tile_store_swz(sKb[buf ^ 1], rk, tid);
+            tile_store_pad(sVb[buf ^ 1], rv, tid);
+            if (k0 + 2 * AT_T < kend) {  // and fetch the one after it, in flight during this tile's MFMAs
+                rk = tile_load(p.qkv + qkv_off(p, b, k0 + 2 * AT_T, 1, h), srow, p.S - k0 - 2 * AT_T, tid);
+                rv = tile_load(p.qkv + qkv_off(p, b, k0 + 2 * AT_T, 2, h), srow, p.S - k0 - 2 * AT_T, tid);
+            }
         }
         if (k0 >= wave_kend) continue;  // every key of this tile is masked for every query of this wave
         f32x4 s[QF][4];
@@ -211,38 +230,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             if (raise) {
                 const float mn = fmaxf(m[f], mx);
                 const float alpha = fast_exp2(m[f] - mn);
-                l[f] *= alpha;
+                l[f][0] *= alpha;
                 m[f] = mn;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[f][dt][e] *= alpha;
             }
-            float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = fast_exp2(fmaf(s[f][t][e], p.scale_log2, -m[f]));  // masked scores are -1e30: 2^-huge = 0
-                    s[f][t][e] = pv;
-                    rs += pv;
-                }
-            l[f] += group_sum(rs);
+                for (int e = 0; e < 4; ++e)
+                    s[f][t][e] = fast_exp2(fmaf(s[f][t][e], p.scale_log2, -m[f]));  // masked scores are -1e30: 2^-huge = 0
         }
+        bf16x8 pf[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                pf[f][kp] = pack_pair(s[f][2 * kp], s[f][2 * kp + 1]);
+                l[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[f][kp], l[f], 0, 0, 0);
+            }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 const bf16x8 vf = frag_tr(sV, kp * 32, dt * 16, lane);
 #pragma unroll
-                for (int f = 0; f < QF; ++f)
-                    o[f][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pack_pair(s[f][2 * kp], s[f][2 * kp + 1]), o[f][dt], 0, 0, 0);
+                for (int f = 0; f < QF; ++f) o[f][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f][kp], o[f][dt], 0, 0, 0);
             }
     }
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         if (qrow[f] < p.S) {
-            const float inv = l[f] > 0.f ? 1.f / l[f] : 0.f;
+            const float lt = l[f][0];
+            const float inv = lt > 0.f ? 1.f / lt : 0.f;
             bf16* op = p.out + ((static_cast<size_t>(b) * p.S + qrow[f]) * p.H + h) * AT_D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 *reinterpret_cast<bf16x4*>(op + dt * 16 + g * 4) = v;
             }
             if (g == 0)
-                p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow[f]] = (m[f] + log2f(fmaxf(l[f], 1e-30f))) * 0.6931471805599453f;
+                p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow[f]] = (m[f] + log2f(fmaxf(lt, 1e-30f))) * 0.6931471805599453f;
         }
     }
 }
