@@ -109,13 +109,25 @@ __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
 // 2^x by the bare hardware instruction: arguments here are <= ~8 and results below 2^-126 may flush to zero
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-__device__ __forceinline__ float group_max(float v) {  // across the four 16-lane groups (same lane & 15)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions across the four 16-lane groups (same lane & 15) with the gfx950 row-swap instructions: after
+// v_permlane16_swap (v_permlane32_swap) of two copies of v, one copy holds the even rows (lower half) in every
+// row (half) and the other the odd rows (upper half), so one max / add finishes a butterfly step on the vector ALU;
+// the generic shuffle goes through the LDS crossbar instead (ds_bpermute, an order of magnitude more latency).
+__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float group_max(float v) {
+    float a = v, b = v;
+    swap_rows16(a, b);
+    a = b = fmaxf(a, b);
+    swap_rows32(a, b);
+    return fmaxf(a, b);
 }
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    float a = v, b = v;
+    swap_rows16(a, b);
+    a = b = a + b;
+    swap_rows32(a, b);
+    return a + b;
 }
 
 // ------------------------------------------------------------------------------------------------
