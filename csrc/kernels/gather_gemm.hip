@@ -358,7 +358,13 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // 16 result times gelu'(act_src), 32 gelu(result) stored to out2 as well.
 // It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
 // DMA queue (vmcnt(0)) at its use.
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK>
+//
+// PLAIN: single tap at offset (0, 0) that is in bounds for every output pixel (linear layers, 1x1 convolutions of
+// any stride).  The source address of a DMA piece is then the same row pointer advanced by BK elements per
+// K-step, so the loader keeps running 64-bit pointers (one add per piece and stage instead of a dozen vector
+// ALU instructions of bounds checks and index arithmetic) and issues unconditionally - past its last tile from
+// the zero page - which puts loads and MFMAs of a K-step into one basic block for the scheduler to interleave.
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK, bool PLAIN = false>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const GatherGemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -458,6 +464,65 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
     };
 
+    // PLAIN loader state: running source pointer and per-stage advance (BK elements, or 0 on the zero page)
+    const bf16* a_cur[AI];
+    const bf16* b_cur[BI];
+    int a_step[AI], b_step[BI];
+    auto plain_tile = [&](int tile) {
+        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        const bool live = tile < total_tiles;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = tile_m * BM + (wave * AI + i) * PR + lrow;
+            if (live && m < p.M) {
+                const uint32_t img = fastdiv(m, p.div_ab);
+                const uint32_t rem = m - img * (p.OA * p.OB);
+                const uint32_t a = fastdiv(rem, p.div_b);
+                const uint32_t b = rem - a * p.OB;
+                const size_t pixel = static_cast<size_t>(img) * (p.Hin * p.Win) + (a * p.istr) * p.Win + b * p.istr;
+                a_cur[i] = p.A + pixel * p.C + kchunk;
+                a_step[i] = BK;
+            } else {
+                a_cur[i] = p.zeros;
+                a_step[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int n = tile_n * BN + (wave * BI + i) * PR + lrow;
+            if (live && n < p.N) {
+                b_cur[i] = p.B + static_cast<size_t>(n) * p.ldb + p.tap_woff[0] + kchunk;
+                b_step[i] = BK;
+            } else {
+                b_cur[i] = p.zeros;
+                b_step[i] = 0;
+            }
+        }
+    };
+    auto plain_issue = [&]() {
+        bf16* sA = ring + ld_slot * STAGE;
+        bf16* sB = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)a_cur[i], (lds_void_t*)(sA + (wave * AI + i) * PR * BK), 16, 0, 0);
+            a_cur[i] += a_step[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)b_cur[i], (lds_void_t*)(sB + (wave * BI + i) * PR * BK), 16, 0, 0);
+            b_cur[i] += b_step[i];
+        }
+        ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
+    };
+    auto plain_advance = [&]() {
+        ld_c0 += BK;
+        if (ld_c0 >= p.C) {
+            ld_c0 = 0;
+            ld_tile += G;
+            plain_tile(ld_tile);
+        }
+    };
+
     f32x4 acc[FM][FN];
     auto compute = [&](int slot) {
         const bf16* sA = ring + slot * STAGE;
@@ -532,7 +597,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     };
 
-    if (total_steps > 0) {
+    if constexpr (PLAIN) {
+        plain_tile(first);
+#pragma unroll
+        for (int k = 0; k < NS - 1; ++k) {
+            plain_issue();
+            plain_advance();
+        }
+    } else if (total_steps > 0) {
         loader_tile(first);
 #pragma unroll
         for (int k = 0; k < NS - 1; ++k)
@@ -550,12 +622,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int s = 0; s < nsteps; ++s, ++g) {
-            // stage g was issued NS - 1 steps ago; in steady state NS - 2 younger stages stay in flight
-            if (ld_issued - (g + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
-            else wait_vm_and_barrier<0>();
-            // every wave has finished reading the stage of step g - 1: refill it
-            if (ld_issued < total_steps) issue_stage();
-            compute(slot);
+            if constexpr (PLAIN) {
+                // NS - 1 stages are always in flight here (the loader never stops issuing)
+                wait_vm_and_barrier<(NS - 2) * LPW>();
+                plain_issue();
+                compute(slot);
+                plain_advance();
+            } else {
+                // stage g was issued NS - 1 steps ago; in steady state NS - 2 younger stages stay in flight
+                if (ld_issued - (g + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
+                else wait_vm_and_barrier<0>();
+                // every wave has finished reading the stage of step g - 1: refill it
+                if (ld_issued < total_steps) issue_stage();
+                compute(slot);
+            }
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
 
@@ -671,6 +751,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
     }
     flush_stats();
+    if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing zero-page stages
 }
 
 static int pdt_num_cus() {
@@ -684,12 +765,23 @@ static int pdt_num_cus() {
     return cus;
 }
 
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN>
+static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream);
+
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK>
 static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stream) {
+    // one tap at (0, 0), in bounds for every output pixel: the pointer-walking loader applies
+    const bool plain = a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && (a.OA - 1) * a.istr < a.Hin && (a.OB - 1) * a.istr < a.Win;
+    if (plain) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, true>(a, stream);
+    return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, false>(a, stream);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN>
+static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream) {
     if ((a.C % BK) != 0) return -1;
     constexpr size_t lds = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
-    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK>;
+    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK, PLAIN>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -990,7 +1082,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // MODE 0: the column axis of the weight tile is the flattened (tap, channel) index, so a tile may span several
 //         taps (a 64-channel 3x3 layer puts four taps into one 256-wide tile and reads dY once for them).
 // MODE 1: packed rows of a few-channel convolution (see gather_gemm_kernel): column = (kernel row, position).
-template <int BN, int BC, int WN, int WC, int NS, int MODE>
+// PLAIN (MODE 0 only): one tap at (0, 0), stride 1, output grid = input grid, i.e. output pixel m reads input
+// pixel m (linear layers, 1x1 stride-1 convolutions).  Both operands are then walked with running pointers that
+// advance by 64 rows per stage, and the loader issues unconditionally (rows beyond the split's range come
+// from the zero page), which leaves one basic block per K-step (see gather_gemm_ring_kernel).
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
     constexpr int KM = 64;                       // pixels per K-step
     constexpr int NW = WN * WC;
@@ -1092,6 +1188,47 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
     };
 
+    // PLAIN loader state
+    const bf16* y_ptr[YI];
+    const bf16* x_ptr[XI];
+    size_t y_adv[YI], x_adv[XI];
+    if constexpr (PLAIN) {
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            const int row = (wave * YI + i) * YR + y_lr;
+            const int c = ((((y_pc >> 1) ^ swz_y(row)) << 1) | (y_pc & 1)) * 8;
+            const bool ok = n0 + c < p.N;
+            y_ptr[i] = ok ? p.dY + static_cast<size_t>(ms + row) * p.ldy + n0 + c : p.zeros;
+            y_adv[i] = ok ? static_cast<size_t>(KM) * p.ldy : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * XR + x_lr;
+            const bool ok = x_dh[i] > -(1 << 23);
+            x_ptr[i] = ok ? p.X + static_cast<size_t>(ms + row) * p.C + x_cc[i] : p.zeros;
+            x_adv[i] = ok ? static_cast<size_t>(KM) * p.C : 0;
+        }
+    }
+    auto plain_issue = [&]() {
+        const int mbase = ms + ld_issued * KM;
+        bf16* sY = ring + ld_slot * STAGE;
+        bf16* sX = sY + KM * BN;
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            const bool ok = mbase + (wave * YI + i) * YR + y_lr < me;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(ok ? y_ptr[i] : p.zeros), (lds_void_t*)(sY + (wave * YI + i) * YR * BN), 16, 0, 0);
+            y_ptr[i] += y_adv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const bool ok = mbase + (wave * XI + i) * XR + x_lr < me;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(ok ? x_ptr[i] : p.zeros), (lds_void_t*)(sX + (wave * XI + i) * XR * BC), 16, 0, 0);
+            x_ptr[i] += x_adv[i];
+        }
+        ++ld_issued;
+        ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
+    };
+
     f32x4 acc[FN][FC];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
@@ -1157,20 +1294,28 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     };
 
 #pragma unroll
-    for (int k = 0; k < NS - 1; ++k)
-        if (ld_issued < nsteps) issue_stage();
+    for (int k = 0; k < NS - 1; ++k) {
+        if constexpr (PLAIN) plain_issue();
+        else if (ld_issued < nsteps) issue_stage();
+    }
     int slot = 0;
     int bias_turn = do_bias ? tc : -1;  // counts down to this workgroup's next bias K-step
     for (int s = 0; s < nsteps; ++s) {
-        if (ld_issued - (s + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
-        else wait_vm_and_barrier<0>();
-        if (ld_issued < nsteps) issue_stage();
+        if constexpr (PLAIN) {
+            wait_vm_and_barrier<(NS - 2) * LPW>();  // NS - 1 stages are always in flight here
+            plain_issue();
+        } else {
+            if (ld_issued - (s + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
+            else wait_vm_and_barrier<0>();
+            if (ld_issued < nsteps) issue_stage();
+        }
         const bool bias_step = bias_turn == 0;
         compute(slot, bias_step);
         if (do_bias) bias_turn = bias_step ? tiles_c - 1 : bias_turn - 1;
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
 
+    if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing zero-page stages
     if (do_bias && (lane & 15) == 0) {  // every column of accb holds the same sums: take column 0
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -1204,12 +1349,25 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     }
 }
 
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
+static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream);
+
 template <int BN, int BC, int WN, int WC, int NS, int MODE = 0>
 static int launch_wgrad_ring(const WgradArgs& a, int gy, hipStream_t stream) {
+    if constexpr (MODE == 0) {
+        // output pixel m reads input pixel m: the pointer-walking loader applies
+        if (a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && a.istr == 1 && a.OA == a.Hin && a.OB == a.Win)
+            return launch_wgrad_ring_plain<BN, BC, WN, WC, NS, MODE, true>(a, gy, stream);
+    }
+    return launch_wgrad_ring_plain<BN, BC, WN, WC, NS, MODE, false>(a, gy, stream);
+}
+
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
+static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream) {
     constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
     if (a.zeros == nullptr) return -1;
-    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE>;
+    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE, PLAIN>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
