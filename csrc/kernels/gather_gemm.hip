@@ -453,13 +453,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
         ++ld_issued;
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
+    };
+    // Moves the loader's cursor to the next (channel block, tap, tile).  Past the last tile the row indices fall
+    // beyond M, so every A piece comes from the zero page and the loader can keep issuing unconditionally.
+    auto advance_cursor = [&]() {
         ld_c0 += BK;
         if (ld_c0 >= p.C) {
             ld_c0 = 0;
             if (++ld_t == p.T) {
                 ld_t = 0;
                 ld_tile += G;
-                if (ld_tile < total_tiles) loader_tile(ld_tile);
+                loader_tile(ld_tile);
             }
         }
     };
@@ -604,11 +608,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             plain_issue();
             plain_advance();
         }
-    } else if (total_steps > 0) {
+    } else {
         loader_tile(first);
 #pragma unroll
-        for (int k = 0; k < NS - 1; ++k)
-            if (ld_issued < total_steps) issue_stage();
+        for (int k = 0; k < NS - 1; ++k) {
+            issue_stage();
+            advance_cursor();
+        }
     }
 
     int g = 0, slot = 0;
@@ -629,12 +635,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 compute(slot);
                 plain_advance();
             } else {
-                // stage g was issued NS - 1 steps ago; in steady state NS - 2 younger stages stay in flight
-                if (ld_issued - (g + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
-                else wait_vm_and_barrier<0>();
+                // stage g was issued NS - 1 steps ago; NS - 2 younger stages stay in flight
+                wait_vm_and_barrier<(NS - 2) * LPW>();
                 // every wave has finished reading the stage of step g - 1: refill it
-                if (ld_issued < total_steps) issue_stage();
+                issue_stage();
                 compute(slot);
+                advance_cursor();
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
     }
     flush_stats();
-    if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing zero-page stages
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing stages
 }
 
 static int pdt_num_cus() {
