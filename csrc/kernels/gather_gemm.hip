@@ -1092,8 +1092,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // pixel m (linear layers, 1x1 stride-1 convolutions).  Both operands are then walked with running pointers that
 // advance by 64 rows per stage, and the loader issues unconditionally (rows beyond the split's range come
 // from the zero page), which leaves one basic block per K-step (see gather_gemm_ring_kernel).
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false>
-__global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
+// `block` is the workgroup's index inside its problem's grid of gx x (nblocks / gx) workgroups.
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
+__device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, int gx, int nblocks) {
     constexpr int KM = 64;                       // pixels per K-step
     constexpr int NW = WN * WC;
     constexpr int TN = BN / WN, TC = BC / WC;    // per-wave tile
@@ -1114,9 +1115,9 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     const int KC = p.T * p.C;  // columns of the weight gradient (MODE 1: C is the row width tw)
     const int tiles_c = (KC + BC - 1) / BC;
     // workgroups of one pixel range share their operand rows: consecutive logical ids, one XCD (see wgrad_kernel)
-    const int lin = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-    const int bid = lin % gridDim.x;
-    const int split = lin / gridDim.x;
+    const int lin = xcd_remap(block, nblocks);
+    const int bid = lin % gx;
+    const int split = lin / gx;
     const int tc = bid % tiles_c, tn = bid / tiles_c;
     const int n0 = tn * BN, c0 = tc * BC;
     const int ms = split * p.m_per_split;
@@ -1355,6 +1356,23 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArg
     }
 }
 
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false>
+__global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
+    wgrad_ring_body<BN, BC, WN, WC, NS, MODE, PLAIN>(p, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.x * gridDim.y);
+}
+
+// Two independent weight-gradient problems of the same tile shape in one launch (workgroups [0, n0) belong to the
+// first).  A workgroup's fp32 atomics are fire-and-forget, so when the first problem's workgroups retire the
+// second problem's main loops start on the freed CUs while those atomics are still draining at the L2: the
+// atomic tail of the first problem - a quarter of its run time on transformer shapes - is no longer exposed.
+template <int BN, int BC, int WN, int WC, int NS>
+__global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_dual_kernel(const WgradArgs p0, const WgradArgs p1, int gx0, int n0,
+                                                                      int gx1, int n1) {
+    const int b = blockIdx.x;
+    if (b < n0) wgrad_ring_body<BN, BC, WN, WC, NS, 0, true>(p0, b, gx0, n0);
+    else wgrad_ring_body<BN, BC, WN, WC, NS, 0, true>(p1, b - n0, gx1, n1);
+}
+
 template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
 static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream);
 
@@ -1383,6 +1401,69 @@ static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t strea
     const int gx = pdt_cdiv(a.N, BN) * pdt_cdiv(a.T * a.C, BC);
     hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(WN * WC * 64), lds, stream, a);
     return pdt_launch_status();
+}
+
+static bool wgrad_is_plain(const WgradArgs& a) {
+    return a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && a.istr == 1 && a.OA == a.Hin && a.OB == a.Win;
+}
+
+template <int BN, int BC, int WN, int WC, int NS>
+static int launch_wgrad_ring_dual(const WgradArgs& a0, int gy0, const WgradArgs& a1, int gy1, hipStream_t stream) {
+    constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16);
+    auto kernel = wgrad_ring_dual_kernel<BN, BC, WN, WC, NS>;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured = true;
+    }
+    const int gx0 = pdt_cdiv(a0.N, BN) * pdt_cdiv(a0.T * a0.C, BC), gx1 = pdt_cdiv(a1.N, BN) * pdt_cdiv(a1.T * a1.C, BC);
+    hipLaunchKernelGGL(kernel, dim3(gx0 * gy0 + gx1 * gy1), dim3(WN * WC * 64), lds, stream, a0, a1, gx0, gx0 * gy0, gx1, gx1 * gy1);
+    return pdt_launch_status();
+}
+
+// Launch grouping: between pdt_wgrad_group_begin() and pdt_wgrad_group_end() ring-kernel launches are recorded
+// instead of issued; the end call issues pairs of compatible problems (same tile shape, both single-tap) as one
+// dual launch and everything else one by one, in recording order.  The operands must stay valid until then.
+struct WgradPending {
+    WgradArgs a;
+    int tile, gy;
+};
+static thread_local bool wgrad_grouping = false;
+static thread_local int wgrad_npending = 0;
+static thread_local WgradPending wgrad_pending[4];
+
+static int wgrad_launch_one(const WgradArgs& a, int tile, int gy, hipStream_t s);
+
+PDT_API void pdt_wgrad_group_begin() {
+    wgrad_grouping = true;
+    wgrad_npending = 0;
+}
+
+PDT_API int pdt_wgrad_group_end(void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    wgrad_grouping = false;
+    int rc = 0, i = 0;
+    while (i < wgrad_npending && rc == 0) {
+        const WgradPending& u = wgrad_pending[i];
+        if (i + 1 < wgrad_npending && wgrad_pending[i + 1].tile == u.tile && wgrad_is_plain(u.a) && wgrad_is_plain(wgrad_pending[i + 1].a)) {
+            const WgradPending& v = wgrad_pending[i + 1];
+            int r = -2;
+            if (u.tile == 10) r = launch_wgrad_ring_dual<128, 128, 2, 4, 4>(u.a, u.gy, v.a, v.gy, s);
+            else if (u.tile == 11) r = launch_wgrad_ring_dual<256, 128, 4, 2, 3>(u.a, u.gy, v.a, v.gy, s);
+            else if (u.tile == 12) r = launch_wgrad_ring_dual<128, 256, 2, 4, 3>(u.a, u.gy, v.a, v.gy, s);
+            else if (u.tile == 16) r = launch_wgrad_ring_dual<256, 256, 2, 4, 2>(u.a, u.gy, v.a, v.gy, s);
+            if (r != -2) {
+                rc = r;
+                i += 2;
+                continue;
+            }
+        }
+        rc = wgrad_launch_one(u.a, u.tile, u.gy, s);
+        ++i;
+    }
+    wgrad_npending = 0;
+    return rc;
 }
 
 // dW must be zero (or hold a value to accumulate onto) before the call.
@@ -1432,6 +1513,14 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (wgrad_grouping && (tile == 10 || tile == 11 || tile == 12 || tile == 16) && wgrad_npending < 4) {
+        if (a.zeros == nullptr) return -1;
+        wgrad_pending[wgrad_npending].a = a;
+        wgrad_pending[wgrad_npending].tile = tile;
+        wgrad_pending[wgrad_npending].gy = gy;
+        ++wgrad_npending;
+        return 0;
+    }
     if (tile == 15) {
         return launch_wgrad_ring<64, 256, 2, 4, 3, 1>(a, gy, s);
     } else if (smallc) {
@@ -1465,4 +1554,12 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         return -1;
     }
     return pdt_launch_status();
+}
+
+static int wgrad_launch_one(const WgradArgs& a, int tile, int gy, hipStream_t s) {
+    if (tile == 10) return launch_wgrad_ring<128, 128, 2, 4, 4>(a, gy, s);
+    if (tile == 11) return launch_wgrad_ring<256, 128, 4, 2, 3>(a, gy, s);
+    if (tile == 12) return launch_wgrad_ring<128, 256, 2, 4, 3>(a, gy, s);
+    if (tile == 16) return launch_wgrad_ring<256, 256, 2, 4, 2>(a, gy, s);
+    return -1;
 }

@@ -44,6 +44,9 @@ def _sig(name: str, argtypes):
 _gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp])
+_lib.pdt_wgrad_group_begin.argtypes = []
+_lib.pdt_wgrad_group_begin.restype = None
+_wgrad_group_end = _sig("pdt_wgrad_group_end", [_vp])
 _bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
@@ -410,6 +413,7 @@ WGRAD_ATOMIC_CAP_MB = int(_os.environ.get("PDT_WGRAD_ATOMIC_CAP_MB", "8"))
 WGRAD_MIN_BLOCKS = int(_os.environ.get("PDT_WGRAD_MIN_BLOCKS", "384"))
 
 
+WGRAD_GROUP = int(_os.environ.get("PDT_WGRAD_GROUP", "1"))  # 0: never pair weight-gradient problems into one launch
 WGRAD_RING = int(_os.environ.get("PDT_WGRAD_RING", "1"))  # 0: one-step register-staged kernel everywhere
 # ring kernels hold one workgroup per CU: one full round of workgroups, not two (twice the atomic volume)
 WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "0"))  # 0: the number of CUs
@@ -1093,15 +1097,22 @@ class _GeluMLP(torch.autograd.Function):
         w2t, _ = SHADOWS.dgrad(w2, 1)  # [hd][n]
         dh = torch.empty_like(h)
         _launch_gather_gemm(gp, w2t, dh, None, None, M, hd, n, hd, n, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, gelu_of=h)
-        dw2, db2 = weight_and_bias_grads(gp, g, w2, b2, 3, 4, n, hd)
-        # first layer
+        # both weight gradients in one launch: the second problem's main loops cover the first one's atomic tail
+        if WGRAD_GROUP:
+            _lib.pdt_wgrad_group_begin()
+        try:
+            dw2, db2 = weight_and_bias_grads(gp, g, w2, b2, 3, 4, n, hd)
+            dw1, db1 = weight_and_bias_grads(dh, x2, w1, b1, 1, 2, hd, k)
+        finally:
+            if WGRAD_GROUP:
+                _check(_wgrad_group_end(_stream()), "wgrad (grouped)")
+        # first layer's input gradient
         dx = None
         if ctx.needs_input_grad[0]:
             w1t, _ = SHADOWS.dgrad(w1, 1)  # [k][hd]
             dx = torch.empty((M, k), dtype=torch.bfloat16, device=dev)
             _launch_gather_gemm(dh, w1t, dx, None, None, M, k, hd, k, hd, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
             dx = dx.reshape(*lead, k)
-        dw1, db1 = weight_and_bias_grads(dh, x2, w1, b1, 1, 2, hd, k)
         dres = None
         if ctx.link is not None:
             ctx.link.grad = gp.view(ctx.res_shape)
