@@ -161,8 +161,8 @@ def main():
             "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1) if on_gpu else None,
         }
         # the reference publishes no number (vs_baseline stays null); the same model on stock PyTorch-ROCm
-        # (bench/stock_baseline.py, 1x MI355X) is the self-measured yardstick
-        stock = {"resnet50": 5959.0, "vit_b_16": 3494.3, "gpt2_medium": 180905.5}.get(args.model)
+        # (bench/stock_baseline.py, 1x MI355X, the best of its measured batch sizes) is the self-measured yardstick
+        stock = {"resnet50": 6510.2, "vit_b_16": 3688.0, "gpt2_medium": 194240.0}.get(args.model)
         if stock and on_gpu:
             out["vs_stock_pytorch_rocm_per_gpu"] = round(value / (stock * env.world_size), 3)
         print(json.dumps(out), flush=True)
