@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
     const int kend = p.causal ? min(p.S, q0 + 64 * QF) : p.S;
     // keys this wave needs under a causal mask: up to its own last query (wave-uniform); later tiles are skipped
-    const int wave_kend = p.causal ? min(p.S, q0 + (wave * QF + QF) * 16) : p.S;
+    // (a wave whose first query lies beyond S has nothing to do at all)
+    const int wave_kend = q0 + wave * QF * 16 >= p.S ? 0 : (p.causal ? min(p.S, q0 + (wave * QF + QF) * 16) : p.S);
     TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
     TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
     tile_store_swz(sKb[0], rk, tid);
