@@ -117,3 +117,84 @@ PDT_API int pdt_transpose_w(const float* src, void* dst, int N, int T, int C, vo
                        static_cast<hipStream_t>(stream), src, static_cast<bf16*>(dst), N, T, C);
     return pdt_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same transposition for many weights in one launch (all data-gradient copies of a parameter group right
+// after the optimizer step): 64 x 64 tiles, fp32 rows read as 16-byte vectors, bf16 rows written as 16-byte
+// vectors.  desc[i].tile_start is the first tile of tensor i in the launch-wide tile numbering (ascending).
+// ------------------------------------------------------------------------------------------------
+struct TransposeDesc {
+    const float* src;  // [N][T][C]
+    bf16* dst;         // [C][T][N]
+    int N, T, C;
+    int tile_start;
+};
+
+__global__ __launch_bounds__(256) void transpose_w_multi_kernel(const TransposeDesc* __restrict__ descs, int ntensors) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    int lo = 0, hi = ntensors - 1;  // last tensor whose tile_start <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_start <= static_cast<int>(blockIdx.x)) lo = mid;
+        else hi = mid - 1;
+    }
+    const TransposeDesc d = descs[lo];
+    int local = blockIdx.x - d.tile_start;
+    const int tc = (d.C + 63) >> 6, tn = (d.N + 63) >> 6;
+    const int ci = local % tc;
+    local /= tc;
+    const int ni = local % tn, t = local / tn;
+    const int c0 = ci * 64, n0 = ni * 64;
+    const bool vec_in = (d.C & 3) == 0, vec_out = (d.N & 7) == 0;
+    // load: 64 rows (n) x 16 float4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 4, q = (idx & 15) << 2;
+        const int n = n0 + r, c = c0 + q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n < d.N) {
+            const float* sp = d.src + (static_cast<size_t>(n) * d.T + t) * d.C + c;
+            if (vec_in && c + 3 < d.C) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(sp);
+                v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < d.C) v[e] = sp[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][q + e] = v[e];
+    }
+    __syncthreads();
+    // store: 64 rows (c) x 8 vectors of 8 bf16 along n
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 3, q = (idx & 7) << 3;
+        const int c = c0 + r, n = n0 + q;
+        if (c >= d.C || n >= d.N) continue;
+        bf16* dp = d.dst + (static_cast<size_t>(c) * d.T + t) * d.N + n;
+        if (vec_out && n + 7 < d.N) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(tile[q + e][r]);
+            *reinterpret_cast<bf16x8*>(dp) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n + e < d.N) dp[e] = f32_to_bf16(tile[q + e][r]);
+        }
+    }
+}
+
+PDT_API int pdt_transpose_desc_bytes() { return static_cast<int>(sizeof(TransposeDesc)); }
+
+PDT_API int pdt_transpose_w_multi(const void* descs, int ntensors, int total_tiles, void* stream) {
+    if (ntensors <= 0 || total_tiles <= 0) return -1;
+    hipLaunchKernelGGL(transpose_w_multi_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const TransposeDesc*>(descs), ntensors);
+    return pdt_launch_status();
+}

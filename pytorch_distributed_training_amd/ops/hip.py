@@ -64,6 +64,8 @@ _nchw_to_nhwc = _sig("pdt_nchw_to_nhwc_bf16", [_vp, _vp, _i, _i, _i, _i, _i, _vp
 _pad_pixels = _sig("pdt_pad_pixels", [_vp, _vp] + [_i] * 8 + [_vp])
 _cast_pad = _sig("pdt_cast_pad_f32_bf16", [_vp, _vp, _ll, _i, _i, _vp])
 _transpose_w = _sig("pdt_transpose_w", [_vp, _vp, _i, _i, _i, _vp])
+_transpose_w_multi = _sig("pdt_transpose_w_multi", [_vp, _i, _i, _vp])
+_lib.pdt_transpose_desc_bytes.restype = ctypes.c_int
 _mt_step = _sig("pdt_multi_tensor_step", [_vp, _vp, _i, _i] + [_f] * 9 + [_i, _vp])
 _mt_step_dev = _sig("pdt_multi_tensor_step_dev", [_vp, _vp, _i, _vp, _vp])
 _opt_set_hyper = _sig("pdt_opt_set_hyper", [_vp, _i] + [_f] * 9 + [_i, _vp])
@@ -324,6 +326,52 @@ class ShadowCache:
             if e.fwd is None:
                 e.version = p._version
         return e.dgrad, npad
+
+
+    def refresh_dgrads(self, plan) -> None:
+        """Rebuild, in one launch, the transposed data-gradient copies of the plan's parameters that already exist
+        (they were used by the previous backward pass) - right after the optimizer kernel, instead of one small
+        transpose launch per layer spread over the next backward pass.  The launch table is cached on the plan
+        and rebuilt when a buffer appeared or moved."""
+        import numpy as np
+
+        items = []
+        for p in plan.params:
+            e = self._entries.get(id(p))
+            if e is None or e.ref() is not p or e.dgrad is None or p.dim() not in (2, 4):
+                continue
+            mat = self.physical_matrix(p)
+            if mat.data_ptr() != p.data_ptr():
+                continue  # the physical order needs a copy: left to the lazy path
+            n = mat.shape[0]
+            if n % 64 != 0:
+                continue  # padded rows: lazy path
+            taps = e.dgrad.shape[1] // n
+            c = e.dgrad.shape[0]
+            if taps * c != mat.shape[1]:
+                continue
+            items.append((p, e, n, taps, c))
+        if not items:
+            return
+        key = tuple((p.data_ptr(), e.dgrad.data_ptr()) for p, e, *_ in items)
+        if getattr(plan, "_tr_key", None) != key:
+            assert _lib.pdt_transpose_desc_bytes() == 32
+            tab = np.zeros((len(items), 4), dtype=np.int64)
+            start = 0
+            for i, (p, e, n, taps, c) in enumerate(items):
+                tab[i, 0] = p.data_ptr()
+                tab[i, 1] = e.dgrad.data_ptr()
+                tab[i, 2] = n | (taps << 32)      # int32 N, int32 T
+                tab[i, 3] = c | (start << 32)     # int32 C, int32 tile_start
+                start += -(-n // 64) * -(-c // 64) * taps
+            plan._tr_key = key
+            plan._tr_table = torch.from_numpy(tab).to(items[0][0].device)
+            plan._tr_tiles = start
+        _check(_transpose_w_multi(plan._tr_table.data_ptr(), len(items), plan._tr_tiles, _stream()), "transpose_w_multi")
+        for p, e, *_ in items:
+            e.dgrad_epoch = self.epoch
+            if e.fwd is None:
+                e.version = p._version
 
 
 SHADOWS = ShadowCache()
@@ -1297,6 +1345,7 @@ def multi_tensor_step(plan: MultiTensorPlan, group, hyper_block: Optional[torch.
             "multi_tensor_step",
         )
     note_parameters_updated(plan)
+    SHADOWS.refresh_dgrads(plan)
     ARENA.reset()
 
 

@@ -601,3 +601,34 @@ def test_bn_backward_sums_from_the_dgrad_epilogue_match_the_separate_reduction(h
             res[fused] = (yy.grad.float().clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), w.grad.clone())
         for a, b in zip(res[True], res[False]):
             assert _rel_err(a, b) < 2e-3
+
+
+def test_transposed_weight_copies_are_rebuilt_in_one_launch_after_the_optimizer_step(hip):
+    """The data-gradient kernels read [Cin][taps][Cout] bf16 copies of the weights; once they exist, the optimizer step
+    refreshes all of them with one batched launch, so the next backward pass finds them current."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+
+    torch.manual_seed(9)
+    dev = _dev()
+    conv = nn.Conv2d(64, 128, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    lin = nn.Linear(192, 320).to(dev)
+    params = [conv.weight, lin.weight, lin.bias]
+    opt = FusedOptimizer(params, mode="sgd", lr=0.1, momentum=0.0, weight_decay=0.0)
+    x = ops.to_device_layout(torch.randn(4, 64, 16, 16, device=dev))
+    z = torch.randn(50, 192, device=dev).to(torch.bfloat16)
+    for _ in range(2):
+        opt.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        zi = z.clone().requires_grad_(True)
+        y, _ = hip.conv2d_stats(xi, conv.weight, 1, 1, False, None, None)
+        (y.float().mean() + hip.linear(zi, lin.weight, lin.bias).float().mean()).backward()
+        opt.step()
+        for w, taps in ((conv.weight, 9), (lin.weight, 1)):
+            e = hip.SHADOWS._entries[id(w)]
+            assert e.dgrad_epoch == hip.SHADOWS.epoch  # refreshed by the batched launch, not lazily
+            wt, npad = hip.SHADOWS.dgrad(w, taps)
+            mat = hip.SHADOWS.physical_matrix(w)  # [N][taps*C]
+            n, c = mat.shape[0], mat.shape[1] // taps
+            ref = mat.view(n, taps, c).permute(2, 1, 0).reshape(c, taps * n).to(torch.bfloat16)
+            assert npad == n and torch.equal(wt, ref)
