@@ -107,6 +107,19 @@ def _int_array(vals: Sequence[int]):
     return (ctypes.c_int * max(len(vals), 1))(*vals)
 
 
+_tap_array_cache: Dict[tuple, tuple] = {}
+
+
+def _tap_arrays(taps):
+    """ctypes arrays (dh, dw, weight offset) of a tap list, built once per distinct list."""
+    key = tuple(taps)
+    hit = _tap_array_cache.get(key)
+    if hit is None:
+        hit = _tap_array_cache[key] = (_int_array([t[0] for t in key]), _int_array([t[1] for t in key]),
+                                       _int_array([t[2] for t in key]))
+    return hit
+
+
 # ------------------------------------------------------------------------------------------------
 # zero-initialised scratch (statistic accumulators) and direct gradient accumulation
 # ------------------------------------------------------------------------------------------------
@@ -450,9 +463,7 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
     bn_y = bn_consts = bn_bits = None
     if bn_stat is not None:
         bn_y, bn_consts, bn_bits = bn_stat
-    dh = _int_array([t[0] for t in taps])
-    dw = _int_array([t[1] for t in taps])
-    wo = _int_array([t[2] for t in taps])
+    dh, dw, wo = _tap_arrays(taps)
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
@@ -544,9 +555,7 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         tile = 0 if (N > 64 and C > 64 and not smallc) else 1
         bt = 128 if tile == 0 else 64
         splits = _wgrad_splits(M, N, smallc * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
-    dh = _int_array([t[0] for t in taps])
-    dwi = _int_array([t[1] for t in taps])
-    wo = _int_array([t[2] for t in taps])
+    dh, dwi, wo = _tap_arrays(taps)
     fuse_bias = dbias is not None and tile >= 10 and tile != 15
     _check(
         _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
