@@ -109,6 +109,80 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const bf16* __restric
     }
 }
 
+// Streaming form of the element-wise passes, used when C/8 is a power of two <= 256 (every ResNet width): a
+// workgroup walks tiles of 256*U vectors, so the channel chunk of a thread never changes and the per-channel
+// constants stay in registers; the U loads of a tile are issued before the first use.  Tensors far larger than
+// the caches are read and written with non-temporal accesses.  Measured against the grid-stride form on 2048-image
+// ResNet-50 activations: 4.2-4.9 -> 5.9-6.1 TB/s (bench/stream_rate.hip).
+constexpr int EW_U = 4;
+constexpr long long EW_NT_BYTES = 64ll << 20;
+
+template <bool NT>
+__device__ __forceinline__ bf16x8 ew_load(const bf16* p, long long v) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(p) + v;
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT>
+__device__ __forceinline__ void ew_store(bf16* p, long long v, bf16x8 x) {
+    bf16x8* q = reinterpret_cast<bf16x8*>(p) + v;
+    if (NT) __builtin_nontemporal_store(x, q);
+    else *q = x;
+}
+
+static inline bool ew_tile_ok(int C) {
+    const int cvec = C >> 3;
+    return cvec >= 1 && cvec <= 256 && (cvec & (cvec - 1)) == 0;
+}
+static inline int ew_tile_grid(long long nvec, int u) {
+    const long long g = (nvec + 256ll * u - 1) / (256ll * u);
+    return static_cast<int>(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+template <bool RELU, int IDENT, bool NT>
+__global__ __launch_bounds__(256) void bn_apply_fwd_tile_kernel(const bf16* __restrict__ y, const float* __restrict__ consts,
+                                                               const bf16* __restrict__ ident,
+                                                               const float* __restrict__ iconsts, bf16* __restrict__ out,
+                                                               uint8_t* __restrict__ bits, long long nvec, int C) {
+    const int c = (threadIdx.x & ((C >> 3) - 1)) << 3;
+    float sc[8], sh[8], isc[8], ish[8];
+    load8f(consts + 2 * C + c, sc);
+    load8f(consts + 3 * C + c, sh);
+    if (IDENT == 2) {
+        load8f(iconsts + 2 * C + c, isc);
+        load8f(iconsts + 3 * C + c, ish);
+    }
+    constexpr long long TILE = 256ll * EW_U;
+    for (long long base = blockIdx.x * TILE + threadIdx.x; base < nvec; base += gridDim.x * TILE) {
+        bf16x8 yv[EW_U], iv[EW_U];
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            const long long v = base + u * 256;
+            if (v < nvec) {
+                yv[u] = ew_load<NT>(y, v);
+                if (IDENT != 0) iv[u] = ew_load<NT>(ident, v);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EW_U; ++u) {
+            const long long v = base + u * 256;
+            if (v < nvec) {
+                bf16x8 o;
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float z = bf16_to_f32(yv[u][e]) * sc[e] + sh[e];
+                    if (IDENT == 1) z += bf16_to_f32(iv[u][e]);
+                    if (IDENT == 2) z += bf16_to_f32(iv[u][e]) * isc[e] + ish[e];
+                    o[e] = f32_to_bf16(RELU ? fmaxf(z, 0.f) : z);
+                    m |= (bf16_to_f32(o[e]) > 0.f ? 1u : 0u) << e;
+                }
+                ew_store<NT>(out, v, o);
+                if (bits != nullptr) bits[v] = static_cast<uint8_t>(m);
+            }
+        }
+    }
+}
+
 static inline int ew_grid(long long nvec) {
     long long g = (nvec + 255) / 256;
     return static_cast<int>(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -124,6 +198,30 @@ PDT_API int pdt_bn_apply_fwd(const void* y, const float* consts, const void* ide
     const bf16* id = static_cast<const bf16*>(ident);
     bf16* o = static_cast<bf16*>(out);
     uint8_t* bt = static_cast<uint8_t*>(bits);
+    if (ew_tile_ok(C)) {
+        const dim3 tg(ew_tile_grid(nvec, EW_U)), tb(256);
+        const int id_mode = ident == nullptr ? 0 : (iconsts == nullptr ? 1 : 2);
+        const bool nt = numel * 2 >= EW_NT_BYTES;
+#define PDT_FWD_T(RL, IDM, NTV) \
+    hipLaunchKernelGGL((bn_apply_fwd_tile_kernel<RL, IDM, NTV>), tg, tb, 0, s, yy, consts, id, iconsts, o, bt, nvec, C)
+#define PDT_FWD_T2(RL, IDM)             \
+    do {                                \
+        if (nt) PDT_FWD_T(RL, IDM, true); \
+        else PDT_FWD_T(RL, IDM, false);  \
+    } while (0)
+        if (relu) {
+            if (id_mode == 0) PDT_FWD_T2(true, 0);
+            else if (id_mode == 1) PDT_FWD_T2(true, 1);
+            else PDT_FWD_T2(true, 2);
+        } else {
+            if (id_mode == 0) PDT_FWD_T2(false, 0);
+            else if (id_mode == 1) PDT_FWD_T2(false, 1);
+            else PDT_FWD_T2(false, 2);
+        }
+#undef PDT_FWD_T2
+#undef PDT_FWD_T
+        return pdt_launch_status();
+    }
     const dim3 g(ew_grid(nvec)), b(256);
     if (ident == nullptr) {
         if (relu) hipLaunchKernelGGL((bn_apply_fwd_kernel<true, 0>), g, b, 0, s, yy, consts, id, iconsts, o, bt, nvec, C);
@@ -175,13 +273,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
     if (cok) {
         for (int r = r0 + rl; r < r1; r += 32) {
             const size_t off = static_cast<size_t>(r) * C + c;
-            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + off);
-            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + off);
+            // every operand is read exactly once by this kernel: non-temporal loads keep them out of the caches
+            const bf16x8 dv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(dout + off));
+            const bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y + off));
             bf16x8 ov, y2v;
             unsigned mbits = 0;
-            if (MASK == 1) ov = *reinterpret_cast<const bf16x8*>(out + off);
+            if (MASK == 1) ov = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(out + off));
             if (MASK == 3) mbits = reinterpret_cast<const uint8_t*>(out)[off >> 3];
-            if (SECOND) y2v = *reinterpret_cast<const bf16x8*>(y2 + off);
+            if (SECOND) y2v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y2 + off));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float dz = bf16_to_f32(dv[e]);
@@ -343,6 +442,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     }
 }
 
+template <int MASK, bool WRITE_DZ, bool SECOND, bool NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_tile_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                               const bf16* __restrict__ y, const float* __restrict__ coef,
+                                                               const float* __restrict__ consts, bf16* __restrict__ dy,
+                                                               bf16* __restrict__ dz_out, const bf16* __restrict__ y2,
+                                                               const float* __restrict__ coef2, bf16* __restrict__ dy2,
+                                                               long long nvec, int C) {
+    constexpr int U = SECOND ? 2 : EW_U;
+    const int c = (threadIdx.x & ((C >> 3) - 1)) << 3;
+    float k0[8], k1[8], k2[8], sc[8], sh[8], q0[8], q1[8], q2[8];
+    load8f(coef + c, k0);
+    load8f(coef + C + c, k1);
+    load8f(coef + 2 * C + c, k2);
+    if (MASK == 2) {
+        load8f(consts + 2 * C + c, sc);
+        load8f(consts + 3 * C + c, sh);
+    }
+    if (SECOND) {
+        load8f(coef2 + c, q0);
+        load8f(coef2 + C + c, q1);
+        load8f(coef2 + 2 * C + c, q2);
+    }
+    constexpr long long TILE = 256ll * U;
+    for (long long base = blockIdx.x * TILE + threadIdx.x; base < nvec; base += gridDim.x * TILE) {
+        bf16x8 dv[U], yv[U], ov[U], y2v[U];
+        unsigned mbits[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long v = base + u * 256;
+            if (v < nvec) {
+                dv[u] = ew_load<NT>(dout, v);
+                yv[u] = ew_load<NT>(y, v);
+                if (MASK == 1) ov[u] = ew_load<NT>(out, v);
+                if (MASK == 3) mbits[u] = reinterpret_cast<const uint8_t*>(out)[v];
+                if (SECOND) y2v[u] = ew_load<NT>(y2, v);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long v = base + u * 256;
+            if (v < nvec) {
+                float dz[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = bf16_to_f32(dv[u][e]);
+                    if (MASK == 1) dz[e] = bf16_to_f32(ov[u][e]) > 0.f ? d : 0.f;
+                    else if (MASK == 2) dz[e] = (bf16_to_f32(yv[u][e]) * sc[e] + sh[e]) > 0.f ? d : 0.f;
+                    else if (MASK == 3) dz[e] = ((mbits[u] >> e) & 1u) ? d : 0.f;
+                    else dz[e] = d;
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(k0[e] * dz[e] + k1[e] * bf16_to_f32(yv[u][e]) + k2[e]);
+                ew_store<NT>(dy, v, o);
+                if (WRITE_DZ) {
+                    bf16x8 z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[e] = f32_to_bf16(dz[e]);
+                    ew_store<NT>(dz_out, v, z);
+                }
+                if (SECOND) {
+                    bf16x8 o2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o2[e] = f32_to_bf16(q0[e] * dz[e] + q1[e] * bf16_to_f32(y2v[u][e]) + q2[e]);
+                    ew_store<NT>(dy2, v, o2);
+                }
+            }
+        }
+    }
+}
+
 // mask_mode as in pdt_bn_bwd_reduce; `consts` ([4][C] from bn_finalize) is needed for mask_mode 2.
 PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, const float* coef, const float* consts,
                              void* dy, void* dz_out, const void* y2, const float* coef2, void* dy2, long long numel,
@@ -358,8 +528,20 @@ PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, c
     const bf16 *d = static_cast<const bf16*>(dout), *o = static_cast<const bf16*>(out), *yy = static_cast<const bf16*>(y),
                *yy2 = static_cast<const bf16*>(y2);
     bf16 *pdy = static_cast<bf16*>(dy), *pdz = static_cast<bf16*>(dz_out), *pdy2 = static_cast<bf16*>(dy2);
-#define PDT_APPLY(MK, WZ, SC) \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, WZ, SC>), g, b, 0, s, d, o, yy, coef, consts, pdy, pdz, yy2, coef2, pdy2, nvec, C)
+    const bool tile = ew_tile_ok(C), nt = numel * 2 >= EW_NT_BYTES;
+    const dim3 tg(ew_tile_grid(nvec, y2 != nullptr ? 2 : EW_U));
+#define PDT_APPLY(MK, WZ, SC)                                                                                              \
+    do {                                                                                                                   \
+        if (!tile)                                                                                                         \
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, WZ, SC>), g, b, 0, s, d, o, yy, coef, consts, pdy, pdz, yy2, coef2, \
+                               pdy2, nvec, C);                                                                             \
+        else if (nt)                                                                                                       \
+            hipLaunchKernelGGL((bn_bwd_apply_tile_kernel<MK, WZ, SC, true>), tg, b, 0, s, d, o, yy, coef, consts, pdy, pdz, \
+                               yy2, coef2, pdy2, nvec, C);                                                                 \
+        else                                                                                                               \
+            hipLaunchKernelGGL((bn_bwd_apply_tile_kernel<MK, WZ, SC, false>), tg, b, 0, s, d, o, yy, coef, consts, pdy,     \
+                               pdz, yy2, coef2, pdy2, nvec, C);                                                            \
+    } while (0)
 #define PDT_APPLY_M(MK)                                   \
     do {                                                  \
         if (dz_out != nullptr) PDT_APPLY(MK, true, false); \
