@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--optimizer", type=str, default="")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--cpu", action="store_true", help="plumbing check on CPU/gloo (not a valid benchmark)")
+    ap.add_argument("--no-dp", action="store_true", help="single process: skip the one-rank data-parallel wrap")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed diagnostics after the timed steps")
     return ap.parse_args()
 
 
@@ -48,7 +50,23 @@ def main():
     from pytorch_distributed_training_amd.parallel import init_distributed, shutdown, wrap_data_parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    env = init_distributed(world > 1, use_cpu=args.cpu)
+    if world == 1 and "RANK" not in os.environ and torch.cuda.is_available() and not args.cpu and not args.no_dp:
+        # a plain `python bench.py` on one GPU still runs the data-parallel path (own RCCL communicator, bucket
+        # launches from the gradient hooks, event-ordered optimizer step) with a one-rank group, so the 1-GPU
+        # number carries the same per-step bookkeeping as the N-GPU numbers it is compared with
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        try:
+            env = init_distributed(True, use_cpu=False)
+        except Exception as e:  # no usable process group on this box: time the unwrapped model
+            print(f"warning: one-rank process group unavailable ({e}); running without the reducer", file=sys.stderr)
+            env = init_distributed(False, use_cpu=False)
+    else:
+        env = init_distributed(world > 1, use_cpu=args.cpu)
     if env.world_size != args.gpus and env.is_main:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {env.world_size}", file=sys.stderr)
     dev = env.device
@@ -119,7 +137,7 @@ def main():
         loss = step(i)
     sync()
     elapsed = time.perf_counter() - t0
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_gpu else "cpu")
     if env.distributed:
@@ -127,6 +145,40 @@ def main():
             t = t.to(torch.float32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
+
+    # Untimed diagnostics (every rank takes part): the same step with the gradient all-reduce switched off, and
+    # the all-reduce rate of the reducer's communicator over message sizes.  They tell how much of the collective
+    # is hidden behind backward and what the links deliver; the headline number above is not affected.
+    extras = {}
+    if env.distributed and on_gpu and not args.no_extras:
+        try:
+            n_local = max(2, min(5, args.steps))
+            with model.no_sync():
+                step(0)
+                sync()
+                t1 = time.perf_counter()
+                for i in range(n_local):
+                    step(i)
+                sync()
+                local_ms = 1e3 * (time.perf_counter() - t1) / n_local
+            zero_grad()
+            extras["ms_per_step_without_allreduce"] = round(local_ms, 3)
+            extras["allreduce_exposed_ms"] = round(1e3 * elapsed / args.steps - local_ms, 3)
+            extras["buckets"] = model.reducer.bucket_summary()
+            extras["transport"] = type(model.transport).__name__
+            comm = getattr(model.transport, "comm", None)
+            if comm is not None and env.world_size > 1:
+                sweep = {}
+                for mib in (1, 4, 16, 64, 256):
+                    buf = torch.zeros(mib * 262144, dtype=torch.float32, device=dev)
+                    us = comm.time_all_reduce(buf, warmup=3, iters=10)
+                    alg = mib * 1048576 / us / 1e3  # GB/s
+                    sweep[f"{mib}MiB"] = {"us": round(us, 1), "algbw_GBps": round(alg, 1),
+                                          "busbw_GBps": round(alg * 2 * (env.world_size - 1) / env.world_size, 1)}
+                    del buf
+                extras["allreduce_sweep_fp32"] = sweep
+        except Exception as e:  # diagnostics must never cost the measurement
+            extras["error"] = repr(e)
 
     per_step_samples = args.batch_size * env.world_size
     unit_scale = args.seq_len if is_lm else 1
@@ -165,6 +217,8 @@ def main():
         stock = {"resnet50": 6510.2, "vit_b_16": 3688.0, "gpt2_medium": 194240.0}.get(args.model)
         if stock and on_gpu:
             out["vs_stock_pytorch_rocm_per_gpu"] = round(value / (stock * env.world_size), 3)
+        if extras:
+            out["extras"] = extras
         print(json.dumps(out), flush=True)
     if env.distributed:
         model.reducer.close()

@@ -158,7 +158,8 @@ def kernels() -> ctypes.CDLL:
     """HIP kernel library; signatures are declared next to their Python wrappers in ``ops``."""
     global _kernels
     if _kernels is None:
-        _kernels = _load("libpdt_kernels.so")
+        # PDT_KERNELS_LIB: file name under _lib/ of an alternative build (kernel A/B experiments)
+        _kernels = _load(os.environ.get("PDT_KERNELS_LIB", "libpdt_kernels.so"))
     return _kernels
 
 
