@@ -578,10 +578,11 @@ class StatLink:
     forward; the convolution side fills ``slots`` in backward when its kernels support it; BatchNorm's backward,
     which runs next, uses ``slots`` if present and reduces by itself otherwise."""
 
-    __slots__ = ("y", "consts", "bits", "slots")
+    __slots__ = ("y", "consts", "bits", "slots", "grad_ptr")
 
     def __init__(self):
         self.y = self.consts = self.bits = self.slots = None
+        self.grad_ptr = 0  # address of the gradient tensor the sums in ``slots`` were taken over
 
 
 def _dgrad_can_fuse_stats(launches) -> bool:
@@ -752,7 +753,7 @@ class _ConvStats(torch.autograd.Function):
                 _launch_gather_gemm(dy, wt, dx, slots, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
                                     oa, ob, h, w_, stride, ph, pw, addend, addend_bits=addend_bits, bn_stat=bn_stat)
             if bn_stat is not None:
-                sl.slots = slots
+                sl.slots, sl.grad_ptr = slots, dx.data_ptr()
         elif ctx.link is not None and ctx.link.grad is not None:
             raise RuntimeError("residual link armed but the convolution input needs no gradient")
         if dx is not None and ctx.link_out is not None and not ctx.link_out.consumed and ctx.link_out.grad is None:
@@ -763,7 +764,11 @@ class _ConvStats(torch.autograd.Function):
 
 
 def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool = True, link=None, link_out=None):
-    return _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out, None)
+    # a block's first convolution (it owns the residual link, so its data-gradient kernel forms the whole gradient
+    # of the block input) also reduces for the BatchNorm of the previous block's tail when that tail left a StatLink
+    # on its output tensor
+    stat_link = getattr(x, "_pdt_stat_link", None) if link is not None else None
+    return _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out, stat_link)
 
 
 def residual_link():
@@ -873,7 +878,7 @@ class _BnAct(torch.autograd.Function):
 
 class _BnAddRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, bn, ident, id_stats, id_gamma, id_beta, id_bn, link=None):
+    def forward(ctx, y, stats, gamma, beta, bn, ident, id_stats, id_gamma, id_beta, id_bn, link=None, stat_link=None):
         y = _as_nhwc(y)
         ident = _as_nhwc(ident)
         if ident.shape != y.shape:
@@ -891,6 +896,11 @@ class _BnAddRelu(torch.autograd.Function):
         ctx.link = link if (link is not None and link.armed and not ctx.projected) else None
         ctx.save_for_backward(y, bits, consts, gamma, beta, ident if ctx.projected else None, iconsts, id_gamma, id_beta)
         ctx.meta = (count, c)
+        ctx.stat_link = None
+        if stat_link is not None and bits is not None and bn.training and not ctx.projected:
+            # offer (y, consts, mask bits) to whichever kernel produces this output's gradient
+            stat_link.y, stat_link.consts, stat_link.bits = y, consts, bits
+            ctx.stat_link = stat_link
         return out
 
     @staticmethod
@@ -901,15 +911,24 @@ class _BnAddRelu(torch.autograd.Function):
         if ctx.projected:
             dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, ident,
                                                                       iconsts, id_gamma, id_beta, mask_mode=3)
-            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None, None
+            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None, None, None
+        slots = None
+        sl = ctx.stat_link
+        if sl is not None:
+            # sums taken by the kernel that wrote this very gradient tensor (had autograd added another consumer's
+            # gradient, ``dout`` would be a different tensor and the sums would not cover it)
+            if sl.slots is not None and sl.grad_ptr == dout.data_ptr():
+                slots = sl.slots
+            sl.y = sl.consts = sl.bits = sl.slots = None
         if ctx.link is not None:
             # the shortcut gradient dz = dout * mask is not materialised: the first convolution's data-gradient
             # kernel forms it from (dout, mask bits) while adding it in its epilogue
-            dy, dgamma, dbeta, _ = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, mask_mode=3)
+            dy, dgamma, dbeta, _ = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, mask_mode=3, slots=slots)
             ctx.link.grad, ctx.link.bits = dout, bits
-            return dy, None, dgamma, dbeta, None, None, None, None, None, None, None
-        dy, dgamma, dbeta, dz = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, want_dz=True, mask_mode=3)
-        return dy, None, dgamma, dbeta, None, dz, None, None, None, None, None
+            return dy, None, dgamma, dbeta, None, None, None, None, None, None, None, None
+        dy, dgamma, dbeta, dz = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, want_dz=True, mask_mode=3,
+                                             slots=slots)
+        return dy, None, dgamma, dbeta, None, dz, None, None, None, None, None, None
 
 
 class _BnReluMaxpool(torch.autograd.Function):
@@ -957,8 +976,13 @@ def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int
 
 def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):
     if id_bn is not None:
-        return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn, None)
-    return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None, link)
+        return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn, None,
+                                None)
+    sl = StatLink()
+    out = _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None, link, sl)
+    if sl.y is not None:
+        out._pdt_stat_link = sl  # picked up by the next block's first convolution (conv2d_stats)
+    return out
 
 
 def bn_relu_maxpool(y, stats, bn):

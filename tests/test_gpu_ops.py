@@ -603,6 +603,57 @@ def test_bn_backward_sums_from_the_dgrad_epilogue_match_the_separate_reduction(h
             assert _rel_err(a, b) < 2e-3
 
 
+@pytest.mark.parametrize("tile", [13, 16])
+@pytest.mark.parametrize("second_projected", [False, True])
+def test_block_tail_bn_sums_come_from_the_next_blocks_first_dgrad(hip, monkeypatch, tile, second_projected):
+    """Two residual blocks in a row: the data-gradient kernel of the second block's first convolution (which also
+    adds the shortcut gradient: the tail's of an identity block, the projection's of a down-sampling block)
+    accumulates the backward sums of the first block's tail BatchNorm, so that tail skips its own reduction.
+    Every set of sums a BatchNorm backward receives is compared with a separate reduction over the same gradient
+    (end-to-end gradients of two runs differ by more than that: statistics accumulated with atomics change the
+    last bits of the normalisation constants from run to run)."""
+    from pytorch_distributed_training_amd.models.resnet import Bottleneck, Conv2d
+
+    torch.manual_seed(21)
+    dev = _dev()
+    monkeypatch.setattr(hip, "_TILE_WIDE", tile)
+    monkeypatch.setattr(hip, "_TILE_NARROW", 14)  # ring kernels for the 64-channel layers too, whatever the row count
+    b1 = Bottleneck(256, 64)
+    if second_projected:
+        b2 = Bottleneck(256, 128, 2, nn.Sequential(Conv2d(256, 512, 1, 2, 0), nn.BatchNorm2d(512)))
+    else:
+        b2 = Bottleneck(256, 64)
+    net = nn.Sequential(b1, b2).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    real = hip._bn_backward
+    seen = []
+
+    def spy(dout, out, y, consts, gamma, beta, count, c, *args, **kw):
+        slots, mask_mode = kw.get("slots"), kw.get("mask_mode")
+        if slots is not None:
+            ref = torch.zeros_like(slots)
+            hip._check(hip._bn_bwd_reduce(dout.data_ptr(), hip._ptr(out), y.data_ptr(), consts.data_ptr(), None, None,
+                                          ref.data_ptr(), y.numel() // c, c, mask_mode, hip._stream()), "bn_bwd_reduce")
+            a, b = slots.sum(0), ref.sum(0)
+            assert _rel_err(a[0], b[0]) < 1e-5 and _rel_err(a[1], b[1]) < 1e-5, (mask_mode, c)
+        seen.append((mask_mode, c, slots is not None))
+        return real(dout, out, y, consts, gamma, beta, count, c, *args, **kw)
+
+    monkeypatch.setattr(hip, "_bn_backward", spy)
+    x = hip.to_device_layout(torch.randn(8, 256, 28, 28, device=dev)).requires_grad_(True)
+    out = net(x)
+    out.backward(torch.randn(out.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert torch.isfinite(x.grad.float()).all()
+    # backward order: tail of block 2 (nothing behind it: reduces by itself), its two inner BatchNorms, the tail of
+    # block 1 (mask bits, 256 channels, sums from block 2's first convolution), block 1's inner BatchNorms
+    assert [s_[2] for s_ in seen] == [False, True, True, True, True, True], seen
+    assert seen[3][:2] == (3, 256)
+
+
 def test_transposed_weight_copies_are_rebuilt_in_one_launch_after_the_optimizer_step(hip):
     """The data-gradient kernels read [Cin][taps][Cout] bf16 copies of the weights; once they exist, the optimizer step
     refreshes all of them with one batched launch, so the next backward pass finds them current."""
