@@ -41,8 +41,19 @@ def parse_args():
     return ap.parse_args()
 
 
+def _claim_stdout():
+    """Keep stdout for the one JSON line: the process's file descriptor 1 is pointed at stderr (native libraries -
+    RCCL prints a version banner when a communicator is created - write there directly), and the returned file
+    object writes to the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse_args()
+    result_out = _claim_stdout()
     from pytorch_distributed_training_amd import ops
     from pytorch_distributed_training_amd.data import synthetic_image_batches, synthetic_token_batches
     from pytorch_distributed_training_amd.models import MODELS, build_model
@@ -219,7 +230,7 @@ def main():
             out["vs_stock_pytorch_rocm_per_gpu"] = round(value / (stock * env.world_size), 3)
         if extras:
             out["extras"] = extras
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if env.distributed:
         model.reducer.close()
     shutdown(env)

@@ -829,6 +829,10 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
     return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK>(a, stream);
 }
 
+// Outputs of at least this many bytes are written with non-temporal stores by the ring kernels.
+static long long g_out_nt_bytes = 64ll << 20;
+PDT_API void pdt_set_out_nt_bytes(long long bytes) { g_out_nt_bytes = bytes; }
+
 // Host entry.  Shapes are validated here; the kernel assumes them.
 //   tile: 0 = 128x128, 1 = 128x64 (narrow N), 2 = 256x128... (see switch)
 // Returns 0 on success, -1 on invalid arguments, otherwise a hipError_t.
@@ -860,7 +864,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.bn_bits = static_cast<const uint8_t*>(bn_bits);
     a.stat_rows = bn_y != nullptr ? 3 : 2;
     a.act = act;
-    a.out_nt = static_cast<long long>(M) * N * 2 >= (64ll << 20);
+    a.out_nt = static_cast<long long>(M) * N * 2 >= g_out_nt_bytes;
     a.out2 = static_cast<bf16*>(out2);
     a.act_src = static_cast<const bf16*>(act_src);
     if (bn_y != nullptr && (smallc || tile < 10)) return -1;  // only the ring kernels have this epilogue

@@ -74,11 +74,14 @@ struct PdtRcclBuckets {
 
 static void rccl_launch(void* user, int b) {
     auto* s = static_cast<PdtRcclBuckets*>(user);
+    // A one-rank group has nothing to reduce (sum and mean over one rank are the identity); RCCL would still run
+    // a copy kernel over the whole bucket.  The event chain is kept so the step is ordered as with N ranks.
     bool ok = hip_ok(hipEventRecord(s->ready[b], s->compute), "hipEventRecord(ready)") &&
               hip_ok(hipStreamWaitEvent(s->comm->stream, s->ready[b], 0), "hipStreamWaitEvent(comm)") &&
-              nccl_ok(ncclAllReduce(s->ptr[b], s->ptr[b], static_cast<size_t>(s->count[b]),
-                                    to_nccl_dtype(s->dtype[b]), s->op, s->comm->comm, s->comm->stream),
-                      "ncclAllReduce") &&
+              (s->comm->world == 1 ||
+               nccl_ok(ncclAllReduce(s->ptr[b], s->ptr[b], static_cast<size_t>(s->count[b]),
+                                     to_nccl_dtype(s->dtype[b]), s->op, s->comm->comm, s->comm->stream),
+                       "ncclAllReduce")) &&
               hip_ok(hipEventRecord(s->done[b], s->comm->stream), "hipEventRecord(done)");
     if (!ok) s->errors++;
 }

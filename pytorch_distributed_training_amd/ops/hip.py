@@ -69,6 +69,10 @@ _lib.pdt_transpose_desc_bytes.restype = ctypes.c_int
 _mt_step = _sig("pdt_multi_tensor_step", [_vp, _vp, _i, _i] + [_f] * 9 + [_i, _vp])
 _mt_step_dev = _sig("pdt_multi_tensor_step_dev", [_vp, _vp, _i, _vp, _vp])
 _opt_set_hyper = _sig("pdt_opt_set_hyper", [_vp, _i] + [_f] * 9 + [_i, _vp])
+_lib.pdt_set_out_nt_bytes.argtypes = [_ll]
+_lib.pdt_set_out_nt_bytes.restype = None
+if "PDT_OUT_NT_MB" in _os.environ:  # size from which GEMM outputs are stored non-temporally (tuning knob)
+    _lib.pdt_set_out_nt_bytes(int(float(_os.environ["PDT_OUT_NT_MB"]) * (1 << 20)))
 _lib.pdt_opt_chunk_elems.restype = ctypes.c_int
 _lib.pdt_opt_desc_bytes.restype = ctypes.c_int
 _lib.pdt_opt_chunk_bytes.restype = ctypes.c_int
