@@ -43,6 +43,8 @@ struct GatherGemmArgs {
     const bf16* bn_y;          // pre-normalisation activations, layout of Out
     const float* bn_consts;    // [4][N]: mean, rstd, scale, shift
     const uint8_t* bn_bits;    // ReLU mask bits of the activation (block tails); nullptr: mask = y * scale + shift > 0
+    const bf16* bn_y2;         // tails with a projected shortcut: the shortcut BatchNorm's input (layout of Out) ...
+    const float* bn_consts2;   // ... and constants; the third row of a slot then receives sum dz * xhat2
     int stat_rows;             // rows per slot of `stats`: 2 (forward statistics) or 3 (backward sums)
     // activation fused into the epilogue: 1 = also store gelu(result) to out2 (Out keeps the pre-activation for the
     // backward pass); 2 = multiply the result by gelu'(act_src), act_src being that pre-activation (layout of Out)
@@ -358,7 +360,8 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 
 // EPI selects what the epilogue reads besides the accumulators (bit mask): 1 bias, 2 addend (+ mask bits),
 // 4 BatchNorm-backward sums with the ReLU mask recomputed from bn_y, 8 the same with the mask from bn_bits,
-// 16 result times gelu'(act_src), 32 gelu(result) stored to out2 as well.
+// 16 result times gelu'(act_src), 32 gelu(result) stored to out2 as well, 64 (with 8) sums for a second BatchNorm
+// that shares dz (the shortcut BatchNorm of a projected block tail).
 // It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
 // DMA queue (vmcnt(0)) at its use.
 //
@@ -577,9 +580,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 
     // BatchNorm partial sums of this lane's 8 channels, carried across tiles
     const int ech = lane % CH, erow = lane / CH;
-    float s1[8], s2[8];
+    float s1[8], s2[8], s3[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
     int stats_n0 = -1;
     auto flush_stats = [&]() {
         if (p.stats == nullptr || stats_n0 < 0) return;
@@ -589,6 +592,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             for (int o = CH; o < 64; o <<= 1) {
                 s1[e] += __shfl_xor(s1[e], o, 64);
                 s2[e] += __shfl_xor(s2[e], o, 64);
+                if (EPI & 64) s3[e] += __shfl_xor(s3[e], o, 64);
             }
         }
         const int ncol = stats_n0 + wn * TN + ech * 8;
@@ -598,10 +602,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             for (int e = 0; e < 8; ++e) {
                 __hip_atomic_fetch_add(slot + ncol + e, s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(slot + p.N + ncol + e, s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (EPI & 64) __hip_atomic_fetch_add(slot + 2 * p.N + ncol + e, s3[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
     };
 
     if constexpr (PLAIN) {
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             constexpr int NPS = 16 / RPP;
             size_t pixo[NPS];
             bool rok[NPS];
-            bf16x8 yv[NPS], av[NPS];
+            bf16x8 yv[NPS], av[NPS], y2v[NPS];
             unsigned amb[NPS];
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
@@ -675,6 +680,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 pixo[ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
                            min(ncol, p.N - 8);
                 if (EPI & 12) yv[ps] = *reinterpret_cast<const bf16x8*>(p.bn_y + pixo[ps]);
+                if (EPI & 64) y2v[ps] = *reinterpret_cast<const bf16x8*>(p.bn_y2 + pixo[ps]);
                 if (EPI & 16) yv[ps] = *reinterpret_cast<const bf16x8*>(p.act_src + pixo[ps]);
                 if (EPI & 2) {
                     av[ps] = *reinterpret_cast<const bf16x8*>(p.addend + pixo[ps]);
@@ -748,6 +754,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                             s1[e] += dz;
                             s2[e] += dz * (bf16_to_f32(yv[ps][e]) - mu[e]) * rs[e];
                         }
+                        if (EPI & 64) {
+                            float mu2[8], rs2[8];
+                            *reinterpret_cast<f32x4*>(mu2) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + ncol);
+                            *reinterpret_cast<f32x4*>(mu2 + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + ncol + 4);
+                            *reinterpret_cast<f32x4*>(rs2) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + p.N + ncol);
+                            *reinterpret_cast<f32x4*>(rs2 + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + p.N + ncol + 4);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float dz = ((mb >> e) & 1u) ? bf16_to_f32(v[e]) : 0.f;
+                                s3[e] += dz * (bf16_to_f32(y2v[ps][e]) - mu2[e]) * rs2[e];
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -819,6 +837,10 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
         // BatchNorm-backward sums: after a shortcut addend with the mask bits of a block tail, or alone with the
         // mask recomputed (plain BatchNorm + ReLU between two convolutions)
         if (a.bias != nullptr || a.stats == nullptr || a.bn_consts == nullptr || a.stat_rows != 3) return -1;
+        if (a.bn_y2 != nullptr) {
+            if (a.addend == nullptr || a.bn_bits == nullptr || a.bn_consts2 == nullptr) return -1;
+            return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 74, BK>(a, stream);
+        }
         if (a.addend != nullptr && a.bn_bits != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 10, BK>(a, stream);
         if (a.addend == nullptr && a.bn_bits == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 4, BK>(a, stream);
         return -1;
@@ -841,8 +863,8 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             int ldb, int ldo, int C, int T, int Hin, int Win, int istr, int OA, int OB, int Hout,
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
                             const int* tap_woff, int tile, int smallc, const void* zeros, const void* bn_y,
-                            const float* bn_consts, const void* bn_bits, int act, void* out2, const void* act_src,
-                            void* stream) {
+                            const float* bn_consts, const void* bn_bits, const void* bn_y2, const float* bn_consts2,
+                            int act, void* out2, const void* act_src, void* stream) {
     if (act < 0 || act > 2 || (act == 1 && (out2 == nullptr || bias == nullptr)) || (act == 2 && act_src == nullptr)) return -1;
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
@@ -862,6 +884,9 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.bn_y = static_cast<const bf16*>(bn_y);
     a.bn_consts = bn_consts;
     a.bn_bits = static_cast<const uint8_t*>(bn_bits);
+    a.bn_y2 = static_cast<const bf16*>(bn_y2);
+    a.bn_consts2 = bn_consts2;
+    if (bn_y2 != nullptr && bn_y == nullptr) return -1;
     a.stat_rows = bn_y != nullptr ? 3 : 2;
     a.act = act;
     a.out_nt = static_cast<long long>(M) * N * 2 >= g_out_nt_bytes;

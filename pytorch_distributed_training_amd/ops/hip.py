@@ -41,7 +41,7 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp])
 _lib.pdt_wgrad_group_begin.argtypes = []
@@ -460,19 +460,21 @@ def _pick_tile(m: int, n: int) -> int:
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
                         oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None, gelu_out=None, gelu_of=None) -> None:
-    """``bn_stat = (y, consts, bits_or_None)``: also accumulate BatchNorm-backward sums of the result into ``stats``
+    """``bn_stat = (y, consts, bits_or_None[, y2, consts2])``: also accumulate BatchNorm-backward sums of the result into ``stats``
     ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`).
     ``gelu_out``: tensor (layout of ``out``) that receives gelu(result) while ``out`` keeps the pre-activation.
     ``gelu_of``: pre-activation tensor (layout of ``out``); the result is multiplied by gelu'(gelu_of)."""
-    bn_y = bn_consts = bn_bits = None
+    bn_y = bn_consts = bn_bits = bn_y2 = bn_consts2 = None
     if bn_stat is not None:
-        bn_y, bn_consts, bn_bits = bn_stat
+        bn_y, bn_consts, bn_bits = bn_stat[:3]
+        if len(bn_stat) == 5:  # a second BatchNorm shares dz (projected shortcut): its sums go to the third row
+            bn_y2, bn_consts2 = bn_stat[3:]
     dh, dw, wo = _tap_arrays(taps)
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc),
-                     _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits),
+                     _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _ptr(bn_y2), _ptr(bn_consts2),
                      1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _stream()),
         "gather_gemm",
     )
@@ -582,10 +584,10 @@ class StatLink:
     forward; the convolution side fills ``slots`` in backward when its kernels support it; BatchNorm's backward,
     which runs next, uses ``slots`` if present and reduces by itself otherwise."""
 
-    __slots__ = ("y", "consts", "bits", "slots", "grad_ptr")
+    __slots__ = ("y", "consts", "bits", "y2", "consts2", "slots", "grad_ptr")
 
     def __init__(self):
-        self.y = self.consts = self.bits = self.slots = None
+        self.y = self.consts = self.bits = self.y2 = self.consts2 = self.slots = None
         self.grad_ptr = 0  # address of the gradient tensor the sums in ``slots`` were taken over
 
 
@@ -752,7 +754,7 @@ class _ConvStats(torch.autograd.Function):
                     (sl.bits is not None) == (addend is not None) and \
                     _dgrad_can_fuse_stats([(nb * oa * ob, c) for oa, ob, _, _, _ in launches]):
                 slots = ARENA.alloc((STAT_SLOTS, 3, c), dy.device)
-                bn_stat = (sl.y, sl.consts, sl.bits)
+                bn_stat = (sl.y, sl.consts, sl.bits) if sl.y2 is None else (sl.y, sl.consts, sl.bits, sl.y2, sl.consts2)
             for oa, ob, ph, pw, taps in launches:
                 _launch_gather_gemm(dy, wt, dx, slots, None, nb * oa * ob, c, r * s * npad, c, n, taps, ho, wo, 1,
                                     oa, ob, h, w_, stride, ph, pw, addend, addend_bits=addend_bits, bn_stat=bn_stat)
@@ -901,9 +903,12 @@ class _BnAddRelu(torch.autograd.Function):
         ctx.save_for_backward(y, bits, consts, gamma, beta, ident if ctx.projected else None, iconsts, id_gamma, id_beta)
         ctx.meta = (count, c)
         ctx.stat_link = None
-        if stat_link is not None and bits is not None and bn.training and not ctx.projected:
-            # offer (y, consts, mask bits) to whichever kernel produces this output's gradient
+        if stat_link is not None and bits is not None and bn.training:
+            # offer (y, consts, mask bits) - and the shortcut BatchNorm's input and constants when the shortcut is
+            # projected - to whichever kernel produces this output's gradient
             stat_link.y, stat_link.consts, stat_link.bits = y, consts, bits
+            if ctx.projected:
+                stat_link.y2, stat_link.consts2 = ident, iconsts
             ctx.stat_link = stat_link
         return out
 
@@ -912,10 +917,6 @@ class _BnAddRelu(torch.autograd.Function):
         y, bits, consts, gamma, beta, ident, iconsts, id_gamma, id_beta = ctx.saved_tensors
         count, c = ctx.meta
         dout = _as_nhwc(dout)
-        if ctx.projected:
-            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, ident,
-                                                                      iconsts, id_gamma, id_beta, mask_mode=3)
-            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None, None, None
         slots = None
         sl = ctx.stat_link
         if sl is not None:
@@ -923,7 +924,11 @@ class _BnAddRelu(torch.autograd.Function):
             # gradient, ``dout`` would be a different tensor and the sums would not cover it)
             if sl.slots is not None and sl.grad_ptr == dout.data_ptr():
                 slots = sl.slots
-            sl.y = sl.consts = sl.bits = sl.slots = None
+            sl.y = sl.consts = sl.bits = sl.y2 = sl.consts2 = sl.slots = None
+        if ctx.projected:
+            dy, dgamma, dbeta, (dy2, dgamma2, dbeta2) = _bn_backward(dout, bits, y, consts, gamma, beta, count, c, ident,
+                                                                      iconsts, id_gamma, id_beta, mask_mode=3, slots=slots)
+            return dy, None, dgamma, dbeta, None, dy2, None, dgamma2, dbeta2, None, None, None
         if ctx.link is not None:
             # the shortcut gradient dz = dout * mask is not materialised: the first convolution's data-gradient
             # kernel forms it from (dout, mask bits) while adding it in its epilogue
@@ -979,11 +984,11 @@ def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int
 
 
 def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):
-    if id_bn is not None:
-        return _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn, None,
-                                None)
     sl = StatLink()
-    out = _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None, link, sl)
+    if id_bn is not None:
+        out = _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, id_stats, id_bn.weight, id_bn.bias, id_bn, None, sl)
+    else:
+        out = _BnAddRelu.apply(y, stats, bn.weight, bn.bias, bn, identity, None, None, None, None, link, sl)
     if sl.y is not None:
         out._pdt_stat_link = sl  # picked up by the next block's first convolution (conv2d_stats)
     return out

@@ -604,8 +604,8 @@ def test_bn_backward_sums_from_the_dgrad_epilogue_match_the_separate_reduction(h
 
 
 @pytest.mark.parametrize("tile", [13, 16])
-@pytest.mark.parametrize("second_projected", [False, True])
-def test_block_tail_bn_sums_come_from_the_next_blocks_first_dgrad(hip, monkeypatch, tile, second_projected):
+@pytest.mark.parametrize("blocks", ["identity+identity", "identity+projected", "projected+identity"])
+def test_block_tail_bn_sums_come_from_the_next_blocks_first_dgrad(hip, monkeypatch, tile, blocks):
     """Two residual blocks in a row: the data-gradient kernel of the second block's first convolution (which also
     adds the shortcut gradient: the tail's of an identity block, the projection's of a down-sampling block)
     accumulates the backward sums of the first block's tail BatchNorm, so that tail skips its own reduction.
@@ -618,11 +618,13 @@ def test_block_tail_bn_sums_come_from_the_next_blocks_first_dgrad(hip, monkeypat
     dev = _dev()
     monkeypatch.setattr(hip, "_TILE_WIDE", tile)
     monkeypatch.setattr(hip, "_TILE_NARROW", 14)  # ring kernels for the 64-channel layers too, whatever the row count
-    b1 = Bottleneck(256, 64)
-    if second_projected:
-        b2 = Bottleneck(256, 128, 2, nn.Sequential(Conv2d(256, 512, 1, 2, 0), nn.BatchNorm2d(512)))
+    if blocks == "projected+identity":  # the first tail has two BatchNorms (main branch and projected shortcut)
+        b1 = Bottleneck(256, 128, 2, nn.Sequential(Conv2d(256, 512, 1, 2, 0), nn.BatchNorm2d(512)))
+        b2 = Bottleneck(512, 128)
     else:
-        b2 = Bottleneck(256, 64)
+        b1 = Bottleneck(256, 64)
+        b2 = (Bottleneck(256, 64) if blocks == "identity+identity"
+              else Bottleneck(256, 128, 2, nn.Sequential(Conv2d(256, 512, 1, 2, 0), nn.BatchNorm2d(512))))
     net = nn.Sequential(b1, b2).to(dev).to(memory_format=torch.channels_last)
     with torch.no_grad():
         for m in net.modules():
@@ -634,24 +636,29 @@ def test_block_tail_bn_sums_come_from_the_next_blocks_first_dgrad(hip, monkeypat
 
     def spy(dout, out, y, consts, gamma, beta, count, c, *args, **kw):
         slots, mask_mode = kw.get("slots"), kw.get("mask_mode")
+        y2, consts2 = (args[0], args[1]) if len(args) >= 2 else (None, None)
         if slots is not None:
             ref = torch.zeros_like(slots)
-            hip._check(hip._bn_bwd_reduce(dout.data_ptr(), hip._ptr(out), y.data_ptr(), consts.data_ptr(), None, None,
-                                          ref.data_ptr(), y.numel() // c, c, mask_mode, hip._stream()), "bn_bwd_reduce")
+            hip._check(hip._bn_bwd_reduce(dout.data_ptr(), hip._ptr(out), y.data_ptr(), consts.data_ptr(), hip._ptr(y2),
+                                          hip._ptr(consts2), ref.data_ptr(), y.numel() // c, c, mask_mode, hip._stream()),
+                       "bn_bwd_reduce")
             a, b = slots.sum(0), ref.sum(0)
             assert _rel_err(a[0], b[0]) < 1e-5 and _rel_err(a[1], b[1]) < 1e-5, (mask_mode, c)
-        seen.append((mask_mode, c, slots is not None))
+            if y2 is not None:
+                assert _rel_err(a[2], b[2]) < 1e-5, "sums of the shortcut BatchNorm"
+        seen.append((mask_mode, c, slots is not None, y2 is not None))
         return real(dout, out, y, consts, gamma, beta, count, c, *args, **kw)
 
     monkeypatch.setattr(hip, "_bn_backward", spy)
-    x = hip.to_device_layout(torch.randn(8, 256, 28, 28, device=dev)).requires_grad_(True)
+    x = hip.to_device_layout(torch.randn(8 if blocks != "projected+identity" else 24, 256, 28, 28, device=dev)).requires_grad_(True)
     out = net(x)
     out.backward(torch.randn(out.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
     assert torch.isfinite(x.grad.float()).all()
     # backward order: tail of block 2 (nothing behind it: reduces by itself), its two inner BatchNorms, the tail of
     # block 1 (mask bits, 256 channels, sums from block 2's first convolution), block 1's inner BatchNorms
     assert [s_[2] for s_ in seen] == [False, True, True, True, True, True], seen
-    assert seen[3][:2] == (3, 256)
+    assert seen[3][:2] == (3, 512 if blocks == "projected+identity" else 256)
+    assert seen[3][3] == (blocks == "projected+identity")
 
 
 def test_transposed_weight_copies_are_rebuilt_in_one_launch_after_the_optimizer_step(hip):
