@@ -626,16 +626,44 @@ PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* consts, void* ou
     return pdt_launch_status();
 }
 
-// Backward of the stem tail, fused with the BatchNorm reduction:
+// Backward of the stem tail.  The pooled gradient is never materialised at the input resolution: both passes
+// gather it from (dout, idx), which are a quarter of the input's size and stay cache resident.
 //   dz[n,h,w,c] = [z > 0] * sum over pooling windows whose winning tap is (h,w) of dout
-//   slots[S][3][C] += (sum dz, sum dz*xhat, 0)
+//   pass 1 (reduce): slots[S][3][C] += (sum dz, sum dz*xhat, 0)
+//   pass 2 (apply):  dy = c0*dz + c1*y + c2
 // One thread per (input pixel, 8 channels); workgroup = 32 pixels x 8 chunks (64 channels).
+__device__ __forceinline__ void maxpool_gather(const bf16* __restrict__ dout, const uint8_t* __restrict__ idx, int n, int h,
+                                               int w, int c, int C, int Ho, int Wo, float (&g)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    // windows (oh, ow) that contain (h, w): 2*oh - 1 <= h <= 2*oh + 1
+    const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;
+    const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        if (oh >= Ho) continue;
+        const int r = h - (2 * oh - 1);
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            if (ow >= Wo) continue;
+            const int tap = r * 3 + (w - (2 * ow - 1));
+            const size_t o = ((static_cast<size_t>(n) * Ho + oh) * Wo + ow) * C + c;
+            const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t word = e < 4 ? iv.x : iv.y;
+                const int win = (word >> (8 * (e & 3))) & 0xff;
+                if (win == tap) g[e] += bf16_to_f32(dv[e]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const bf16* __restrict__ dout,
                                                                    const uint8_t* __restrict__ idx,
                                                                    const bf16* __restrict__ y,
                                                                    const float* __restrict__ consts, bf16* __restrict__ dz,
                                                                    float* slots, int NB, int H, int W, int C, int Ho,
-                                                                   int Wo, int pix_per_block) {
+                                                                   int Wo, int pix_per_block, FastDiv div_w, FastDiv div_h) {
     __shared__ float red[32][2][64];
     const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.y * 64 + chunk * 8;
@@ -650,39 +678,18 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const bf16* 
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    const long long npix = static_cast<long long>(NB) * H * W;
-    const long long p0 = static_cast<long long>(blockIdx.x) * pix_per_block;
-    const long long p1 = min(npix, p0 + pix_per_block);
+    const uint32_t npix = static_cast<uint32_t>(NB) * H * W;
+    const uint32_t p0 = blockIdx.x * static_cast<uint32_t>(pix_per_block);
+    const uint32_t p1 = min(npix, p0 + pix_per_block);
     if (cok) {
-        for (long long pix = p0 + rl; pix < p1; pix += 32) {
-            const int w = static_cast<int>(pix % W);
-            const long long t = pix / W;
-            const int h = static_cast<int>(t % H);
-            const int n = static_cast<int>(t / H);
+        for (uint32_t pix = p0 + rl; pix < p1; pix += 32) {
+            const uint32_t t = fastdiv(pix, div_w);
+            const int w = static_cast<int>(pix - t * W);
+            const uint32_t n = fastdiv(t, div_h);
+            const int h = static_cast<int>(t - n * H);
+            const bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y + static_cast<size_t>(pix) * C + c));
             float g[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = 0.f;
-            // windows (oh, ow) that contain (h, w): 2*oh - 1 <= h <= 2*oh + 1
-            const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;
-            const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
-            for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-                if (oh >= Ho) continue;
-                const int r = h - (2 * oh - 1);
-                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                    if (ow >= Wo) continue;
-                    const int tap = r * 3 + (w - (2 * ow - 1));
-                    const size_t o = ((static_cast<size_t>(n) * Ho + oh) * Wo + ow) * C + c;
-                    const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
-                    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + o);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint32_t word = e < 4 ? iv.x : iv.y;
-                        const int win = (word >> (8 * (e & 3))) & 0xff;
-                        if (win == tap) g[e] += bf16_to_f32(dv[e]);
-                    }
-                }
-            }
-            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + pix * C + c);
+            maxpool_gather(dout, idx, static_cast<int>(n), h, w, c, C, Ho, Wo, g);
             bf16x8 zo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const bf16* 
                 s1[e] += d;
                 s2[e] += d * (yf - mu[e]) * rs[e];
             }
-            *reinterpret_cast<bf16x8*>(dz + pix * C + c) = zo;
+            if (dz != nullptr) *reinterpret_cast<bf16x8*>(dz + static_cast<size_t>(pix) * C + c) = zo;
         }
     }
 #pragma unroll
@@ -714,6 +721,7 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const bf16* 
     }
 }
 
+// dz may be nullptr: only the sums are produced (pdt_maxpool_bn_bwd_apply forms dz again on the fly).
 PDT_API int pdt_maxpool_bn_bwd_reduce(const void* dout, const void* idx, const void* y, const float* consts, void* dz,
                                       float* slots, int NB, int H, int W, int C, void* stream) {
     if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
@@ -724,7 +732,59 @@ PDT_API int pdt_maxpool_bn_bwd_reduce(const void* dout, const void* idx, const v
     const dim3 g(pdt_cdiv(npix, ppb), pdt_cdiv(C, 64)), b(256);
     hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, g, b, 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16*>(dout), static_cast<const uint8_t*>(idx), static_cast<const bf16*>(y), consts,
-                       static_cast<bf16*>(dz), slots, NB, H, W, C, Ho, Wo, ppb);
+                       static_cast<bf16*>(dz), slots, NB, H, W, C, Ho, Wo, ppb, make_fastdiv(W), make_fastdiv(H));
+    return pdt_launch_status();
+}
+
+// Second pass: dy = c0*dz + c1*y + c2 with dz gathered from (dout, idx) again.  One thread per (pixel, 8 channels),
+// consecutive threads on consecutive channel chunks, so a wave reads and writes whole contiguous rows.
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const bf16* __restrict__ dout,
+                                                                  const uint8_t* __restrict__ idx,
+                                                                  const bf16* __restrict__ y,
+                                                                  const float* __restrict__ consts,
+                                                                  const float* __restrict__ coef, bf16* __restrict__ dy,
+                                                                  int NB, int H, int W, int C, int Ho, int Wo,
+                                                                  FastDiv div_w, FastDiv div_h, FastDiv div_cvec) {
+    const uint32_t cvec = C >> 3;
+    const uint32_t nvec = static_cast<uint32_t>(NB) * H * W * cvec;
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < nvec; v += gridDim.x * 256u) {
+        const uint32_t pix = fastdiv(v, div_cvec);
+        const int c = static_cast<int>(v - pix * cvec) << 3;
+        const uint32_t t = fastdiv(pix, div_w);
+        const int w = static_cast<int>(pix - t * W);
+        const uint32_t n = fastdiv(t, div_h);
+        const int h = static_cast<int>(t - n * H);
+        const bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y) + v);
+        float sc[8], sh[8], k0[8], k1[8], k2[8], g[8];
+        load8f(consts + 2 * C + c, sc);
+        load8f(consts + 3 * C + c, sh);
+        load8f(coef + c, k0);
+        load8f(coef + C + c, k1);
+        load8f(coef + 2 * C + c, k2);
+        maxpool_gather(dout, idx, static_cast<int>(n), h, w, c, C, Ho, Wo, g);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float yf = bf16_to_f32(yv[e]);
+            const float d = (yf * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+            o[e] = f32_to_bf16(k0[e] * d + k1[e] * yf + k2[e]);
+        }
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dy) + v);
+    }
+}
+
+PDT_API int pdt_maxpool_bn_bwd_apply(const void* dout, const void* idx, const void* y, const float* consts,
+                                     const float* coef, void* dy, int NB, int H, int W, int C, void* stream) {
+    if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long nvec = static_cast<long long>(NB) * H * W * (C / 8);
+    if (nvec >= (1ll << 31)) return -1;
+    long long grid = (nvec + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(static_cast<int>(grid)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(dout), static_cast<const uint8_t*>(idx),
+                       static_cast<const bf16*>(y), consts, coef, static_cast<bf16*>(dy), NB, H, W, C, Ho, Wo,
+                       make_fastdiv(W), make_fastdiv(H), make_fastdiv(C / 8));
     return pdt_launch_status();
 }
 

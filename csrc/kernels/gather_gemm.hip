@@ -679,11 +679,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 const uint32_t b = rem - a * p.OB;
                 pixo[ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
                            min(ncol, p.N - 8);
-                if (EPI & 12) yv[ps] = *reinterpret_cast<const bf16x8*>(p.bn_y + pixo[ps]);
-                if (EPI & 64) y2v[ps] = *reinterpret_cast<const bf16x8*>(p.bn_y2 + pixo[ps]);
-                if (EPI & 16) yv[ps] = *reinterpret_cast<const bf16x8*>(p.act_src + pixo[ps]);
+                // operands with the layout of the output are read once: streamed past the caches when they are large
+                auto ld8 = [&](const bf16* q) {
+                    return p.out_nt ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(q))
+                                    : *reinterpret_cast<const bf16x8*>(q);
+                };
+                if (EPI & 12) yv[ps] = ld8(p.bn_y + pixo[ps]);
+                if (EPI & 64) y2v[ps] = ld8(p.bn_y2 + pixo[ps]);
+                if (EPI & 16) yv[ps] = ld8(p.act_src + pixo[ps]);
                 if (EPI & 2) {
-                    av[ps] = *reinterpret_cast<const bf16x8*>(p.addend + pixo[ps]);
+                    av[ps] = ld8(p.addend + pixo[ps]);
                     amb[ps] = p.addend_bits != nullptr ? p.addend_bits[pixo[ps] >> 3] : 0xffu;
                 }
             }

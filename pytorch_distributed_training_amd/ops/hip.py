@@ -54,6 +54,7 @@ _bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, 
 _bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_relu_maxpool_fwd = _sig("pdt_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _maxpool_bn_bwd_reduce = _sig("pdt_maxpool_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
+_maxpool_bn_bwd_apply = _sig("pdt_maxpool_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _avgpool_fwd = _sig("pdt_avgpool_fwd", [_vp, _vp, _i, _i, _i, _vp])
 _avgpool_bwd = _sig("pdt_avgpool_bwd", [_vp, _vp, _i, _i, _i, _vp])
 _ce_fwd = _sig("pdt_softmax_ce_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp])
@@ -962,14 +963,14 @@ class _BnReluMaxpool(torch.autograd.Function):
         count, c, nb, h, w = ctx.meta
         dout = _as_nhwc(dout)
         dev = y.device
-        dz = torch.empty_like(y)
+        # the un-pooled gradient dz is not written out: both passes gather it from (dout, idx), a quarter of y's size
         slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
-        _check(_maxpool_bn_bwd_reduce(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), dz.data_ptr(),
+        _check(_maxpool_bn_bwd_reduce(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), None,
                                       slots.data_ptr(), nb, h, w, c, _stream()), "maxpool_bn_bwd_reduce")
         dgamma, dbeta, coef = _bn_param_grads(slots, 1, count, gamma, beta, consts, c, dev)
         dy = torch.empty_like(y)
-        _check(_bn_bwd_apply(dz.data_ptr(), None, y.data_ptr(), coef.data_ptr(), consts.data_ptr(), dy.data_ptr(), None,
-                             None, None, None, y.numel(), c, 0, _stream()), "bn_bwd_apply")
+        _check(_maxpool_bn_bwd_apply(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), coef.data_ptr(),
+                                     dy.data_ptr(), nb, h, w, c, _stream()), "maxpool_bn_bwd_apply")
         return dy, None, dgamma, dbeta, None
 
 
