@@ -61,16 +61,17 @@ def main():
     from pytorch_distributed_training_amd.parallel import init_distributed, shutdown, wrap_data_parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and "RANK" not in os.environ and torch.cuda.is_available() and not args.cpu and not args.no_dp:
+    if world == 1 and torch.cuda.is_available() and not args.cpu and not args.no_dp:
         # a plain `python bench.py` on one GPU still runs the data-parallel path (own RCCL communicator, bucket
         # launches from the gradient hooks, event-ordered optimizer step) with a one-rank group, so the 1-GPU
         # number carries the same per-step bookkeeping as the N-GPU numbers it is compared with
-        import socket
+        if "RANK" not in os.environ or "MASTER_PORT" not in os.environ:  # not launched by torchrun
+            import socket
 
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         try:
             env = init_distributed(True, use_cpu=False)
         except Exception as e:  # no usable process group on this box: time the unwrapped model

@@ -125,11 +125,21 @@ class GradReducer:
             [p.numel() for p in ps], [p.element_size() for p in ps], self.first_bucket_bytes, self.bucket_bytes, order
         )
         old_views = self.views
-        self.buckets = []
+        # all buckets of one dtype and device are slices of a single allocation: zero_grad is one memset per group
+        # instead of one per bucket (a GPT-2 medium has 57 buckets of 25 MiB)
+        owner = [ps[next(i for i, bo in enumerate(self.plan.bucket_of) if bo == b)] for b in range(self.plan.n_buckets)]
+        group_elems: Dict[tuple, int] = {}
+        place = []
         for b, nbytes in enumerate(self.plan.bucket_bytes):
-            first = next(i for i, bo in enumerate(self.plan.bucket_of) if bo == b)
-            p0 = ps[first]
-            self.buckets.append(torch.zeros(nbytes // p0.element_size(), dtype=p0.dtype, device=p0.device))
+            p0 = owner[b]
+            key = (p0.dtype, p0.device)
+            n = nbytes // p0.element_size()
+            align = max(1, SLOT_ALIGN_BYTES // p0.element_size())
+            start = (group_elems.get(key, 0) + align - 1) // align * align
+            place.append((key, start, n))
+            group_elems[key] = start + n
+        self._flats = {key: torch.zeros(n, dtype=key[0], device=key[1]) for key, n in group_elems.items()}
+        self.buckets = [self._flats[key][start:start + n] for key, start, n in place]
         self.views = []
         for i, p in enumerate(ps):
             flat = self.buckets[self.plan.bucket_of[i]]
@@ -205,9 +215,9 @@ class GradReducer:
 
     # ------------------------------------------------------------------ user API
     def zero_grad(self) -> None:
-        """Zero every gradient with one memset per bucket (``.grad`` stays a bucket view)."""
-        for b in self.buckets:
-            b.zero_()
+        """Zero every gradient with one memset per dtype (``.grad`` stays a bucket view)."""
+        for flat in self._flats.values():
+            flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
 
