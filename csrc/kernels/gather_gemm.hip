@@ -681,8 +681,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                            min(ncol, p.N - 8);
                 // operands with the layout of the output are read once: streamed past the caches when they are large
                 auto ld8 = [&](const bf16* q) {
-                    return p.out_nt ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(q))
-                                    : *reinterpret_cast<const bf16x8*>(q);
+                    bf16x8 r;
+                    if (p.out_nt) {  // (empty statements: see the output store below)
+                        asm volatile("" ::: "memory");
+                        r = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(q));
+                        asm volatile("" ::: "memory");
+                    } else {
+                        r = *reinterpret_cast<const bf16x8*>(q);
+                    }
+                    return r;
                 };
                 if (EPI & 12) yv[ps] = ld8(p.bn_y + pixo[ps]);
                 if (EPI & 64) y2v[ps] = ld8(p.bn_y2 + pixo[ps]);
@@ -722,8 +729,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(yv[ps][e])));
                     }
-                    if (p.out_nt) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.Out + o));
-                    else *reinterpret_cast<bf16x8*>(p.Out + o) = v;
+                    if (p.out_nt) {
+                        // the empty statements keep the optimizer from merging the two branches' stores into one plain
+                        // store (which loses the cache policy)
+                        asm volatile("" ::: "memory");
+                        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.Out + o));
+                        asm volatile("" ::: "memory");
+                    } else {
+                        *reinterpret_cast<bf16x8*>(p.Out + o) = v;
+                    }
                     if (EPI & 32) {
                         bf16x8 gv;
 #pragma unroll
