@@ -29,7 +29,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-size", type=int, default=2048, help="per-GPU batch (sized for 288 GB of HBM: ~80 GiB at 2048)")
+    ap.add_argument("--batch-size", type=int, default=0,
+                    help="per-GPU batch; 0 = the model's default, sized for 288 GB of HBM (ResNet-50 2048: 81 GiB, "
+                         "ViT-B/16 1024: 60 GiB, GPT-2 medium 32: 37 GiB - its logits tensor is near the 2^31-element limit)")
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=1024)
@@ -51,8 +53,13 @@ def _claim_stdout():
     return real
 
 
+DEFAULT_BATCH = {"resnet50": 2048, "vit_b_16": 1024, "gpt2_medium": 32}
+
+
 def main():
     args = parse_args()
+    if args.batch_size <= 0:
+        args.batch_size = DEFAULT_BATCH.get(args.model, 256)
     result_out = _claim_stdout()
     from pytorch_distributed_training_amd import ops
     from pytorch_distributed_training_amd.data import synthetic_image_batches, synthetic_token_batches
@@ -198,7 +205,8 @@ def main():
     if env.is_main:
         out = {
             "metric": ("tokens/sec (whole job) " if is_lm else "images/sec (whole node) ")
-            + f"{args.model} {'seq ' + str(args.seq_len) if is_lm else str(args.image_size) + '^2'} bf16 training",
+            + f"{args.model} {'seq ' + str(args.seq_len) if is_lm else str(args.image_size) + '^2'} "
+            + f"{'bf16' if on_gpu else 'fp32'} training",
             "value": round(value, 2),
             "unit": "tokens/s" if is_lm else "images/s",
             "n_gpus": env.world_size,
