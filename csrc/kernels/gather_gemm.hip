@@ -938,6 +938,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         // ring variants (persistent, LDS-DMA): need the page of zeros
         case 13: return launch_gather_gemm_ring<256, 128, 4, 2, 3>(a, s);  // 8 waves, 256-row tile
         case 14: return launch_gather_gemm_ring<256, 64, 8, 1, 3>(a, s);   // narrow N, 32x64 per wave
+        case 15: return launch_gather_gemm_ring<512, 64, 8, 1, 2>(a, s);   // narrow N, 64x64 per wave: half the weight-fragment reads per FLOP
         case 16: return launch_gather_gemm_ring<256, 256, 2, 4, 2, 64>(a, s);  // 128x64 per wave, K-step 64, 2 stages
         default: return -1;
     }

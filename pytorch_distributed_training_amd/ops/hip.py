@@ -431,11 +431,11 @@ def _num_cus() -> int:
     return _NUM_CUS
 
 
-def _pick_tile(m: int, n: int) -> int:
+def _pick_tile(m: int, n: int, ksteps: int = 1) -> int:
     """Tile variant of the gather-GEMM kernel for an M x N output.
 
-    0/1/2: one tile per workgroup (128x128, 128x64, 64x64).  13/14/16: persistent workgroups streaming
-    256x128 / 256x64 / 256x256 tiles through an LDS-DMA ring; they win once every CU gets several tiles
+    0/1/2: one tile per workgroup (128x128, 128x64, 64x64).  13/14/15/16: persistent workgroups streaming
+    256x128 / 256x64 / 512x64 / 256x256 tiles through an LDS-DMA ring; they win once every CU gets several tiles
     (measured per layer with bench/conv_bench.py and bench/gemm_bench.py), below that the tail of a partially
     filled last round costs more than it saves.  The 256x256 tile moves a third less operand data per FLOP
     through the L2-to-LDS path, which is what bounds the 256x128 kernel on large GEMMs."""
@@ -444,6 +444,11 @@ def _pick_tile(m: int, n: int) -> int:
             return 2
         if _TILE_NARROW >= 0:
             return _TILE_NARROW
+        if -(-m // 512) >= _RING_MIN_TILES and ksteps >= 2:
+            # 512x64: a wave covers 64 rows, so the weight fragments (re-read by all 8 waves) cost half as many LDS
+            # reads per FLOP as in the 256-row tile; 6-9 % on the 64-channel 3x3 and 1x1 layers with several K-steps,
+            # slower on single-K-step launches (two ring stages instead of three)
+            return 15
         return 14 if -(-m // 256) >= _RING_MIN_TILES else 1  # 256x64 ring once every CU gets several tiles
     if _TILE_WIDE >= 0:
         return _TILE_WIDE
@@ -474,7 +479,8 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
-                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo, _pick_tile(M, N), int(smallc),
+                     Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo,
+                     _pick_tile(M, N, len(taps) * max(C // 64, 1)), int(smallc),
                      _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _ptr(bn_y2), _ptr(bn_consts2),
                      1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _stream()),
         "gather_gemm",

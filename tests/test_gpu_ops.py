@@ -89,9 +89,9 @@ def test_conv_every_wide_tile_variant(hip, monkeypatch, tile, nb, cin, cout, k, 
     test_conv_forward_backward(hip, nb, cin, cout, k, stride, pad, hw)
 
 
-@pytest.mark.parametrize("tile", [1, 14])
+@pytest.mark.parametrize("tile", [1, 14, 15])
 def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
-    """Layers with at most 64 output channels: one 128x64 tile per workgroup, and the 256x64 ring."""
+    """Layers with at most 64 output channels: one 128x64 tile per workgroup, and the 256x64 and 512x64 rings."""
     monkeypatch.setattr(hip, "_TILE_NARROW", tile)
     test_conv_forward_backward(hip, 9, 64, 64, 3, 1, 1, 37)
     test_conv_forward_backward(hip, 6, 256, 64, 1, 1, 0, 56)
