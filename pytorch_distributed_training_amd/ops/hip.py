@@ -452,14 +452,19 @@ def _pick_tile(m: int, n: int, ksteps: int = 1) -> int:
         return 14 if -(-m // 256) >= _RING_MIN_TILES else 1  # 256x64 ring once every CU gets several tiles
     if _TILE_WIDE >= 0:
         return _TILE_WIDE
+    # Ring kernels hold one workgroup per CU, so a launch costs whole rounds of tiles.  A 256x256 tile takes about
+    # 1.65x the time of a 256x128 tile for twice the work; a ring tile is used when its rounds are at least 60 % full,
+    # below that the one-tile-per-workgroup kernel (several workgroups per CU) wastes less.  Calibrated with
+    # `bench/gemm_bench.py --tile-sweep` on the ResNet-50 and transformer shapes.
     cus = _num_cus()
+    t13 = -(-m // 256) * -(-n // 128)
+    r13 = -(-t13 // cus)
     if n >= 256 and -(-n // 256) * 256 <= 1.15 * n:
-        big = -(-m // 256) * -(-n // 256)
-        if big >= 4 * cus or (big >= cus and big >= 0.85 * -(-big // cus) * cus):
+        t16 = -(-m // 256) * -(-n // 256)
+        r16 = -(-t16 // cus)
+        if t16 >= 0.6 * r16 * cus and 1.65 * r16 <= r13:
             return 16
-    tiles = -(-m // 256) * -(-n // 128)
-    rounds = -(-tiles // cus)
-    if tiles >= _RING_MIN_TILES or (tiles >= cus and tiles >= 0.9 * rounds * cus):
+    if t13 >= _RING_MIN_TILES or t13 >= 0.6 * r13 * cus:
         return 13
     return 0
 
