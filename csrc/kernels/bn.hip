@@ -562,7 +562,8 @@ PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, c
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ consts,
                                                                  bf16* __restrict__ out, uint8_t* __restrict__ idx,
-                                                                 int NB, int H, int W, int C, int Ho, int Wo) {
+                                                                 bf16* __restrict__ ywin, int NB, int H, int W, int C,
+                                                                 int Ho, int Wo) {
     const int cvec = C >> 3;
     const long long nvec = static_cast<long long>(NB) * Ho * Wo * cvec;
     for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
@@ -578,10 +579,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
         load8f(consts + 3 * C + c, sh);
         float best[8];
         int bi[8];
+        bf16x8 yw;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             best[e] = -1.f;  // relu output is >= 0, so any in-bounds tap wins over this
             bi[e] = 0;
+            yw[e] = f32_to_bf16(0.f);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
                     if (z > best[e]) {
                         best[e] = z;
                         bi[e] = r * 3 + s;
+                        yw[e] = yv[e];
                     }
                 }
             }
@@ -612,26 +616,28 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
         }
         *reinterpret_cast<bf16x8*>(out + v * 8) = o;
         *reinterpret_cast<uint2*>(idx + v * 8) = make_uint2(lo, hi);
+        if (ywin != nullptr) *reinterpret_cast<bf16x8*>(ywin + v * 8) = yw;
     }
 }
 
-PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* consts, void* out, void* idx, int NB, int H, int W, int C,
-                                    void* stream) {
+// ywin (optional, shape of out): the pre-normalisation value of each window's winner.  BatchNorm's backward sums over
+// the un-pooled gradient equal sums over the pooled one taken at the winners, so they need only (dout, ywin).
+PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* consts, void* out, void* idx, void* ywin, int NB, int H,
+                                    int W, int C, void* stream) {
     if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long nvec = static_cast<long long>(NB) * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_grid(nvec)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16*>(y), consts, static_cast<bf16*>(out), static_cast<uint8_t*>(idx), NB, H, W,
-                       C, Ho, Wo);
+                       static_cast<const bf16*>(y), consts, static_cast<bf16*>(out), static_cast<uint8_t*>(idx),
+                       static_cast<bf16*>(ywin), NB, H, W, C, Ho, Wo);
     return pdt_launch_status();
 }
 
-// Backward of the stem tail.  The pooled gradient is never materialised at the input resolution: both passes
-// gather it from (dout, idx), which are a quarter of the input's size and stay cache resident.
+// Backward of the stem tail.  The pooled gradient is never materialised at the input resolution:
 //   dz[n,h,w,c] = [z > 0] * sum over pooling windows whose winning tap is (h,w) of dout
-//   pass 1 (reduce): slots[S][3][C] += (sum dz, sum dz*xhat, 0)
-//   pass 2 (apply):  dy = c0*dz + c1*y + c2
-// One thread per (input pixel, 8 channels); workgroup = 32 pixels x 8 chunks (64 channels).
+//   pass 1 (sums):  sum dz and sum dz*xhat over input pixels equal the sums of dout*[z_win > 0] and
+//                   dout*[z_win > 0]*xhat(y_win) over pooled outputs: bn_bwd_reduce on (dout, ywin), both pooled-size
+//   pass 2 (apply): dy = c0*dz + c1*y + c2 with dz gathered from (dout, idx), a quarter of y's size
 __device__ __forceinline__ void maxpool_gather(const bf16* __restrict__ dout, const uint8_t* __restrict__ idx, int n, int h,
                                                int w, int c, int C, int Ho, int Wo, float (&g)[8]) {
 #pragma unroll
@@ -656,84 +662,6 @@ __device__ __forceinline__ void maxpool_gather(const bf16* __restrict__ dout, co
             }
         }
     }
-}
-
-__global__ __launch_bounds__(256) void maxpool_bn_bwd_reduce_kernel(const bf16* __restrict__ dout,
-                                                                   const uint8_t* __restrict__ idx,
-                                                                   const bf16* __restrict__ y,
-                                                                   const float* __restrict__ consts, bf16* __restrict__ dz,
-                                                                   float* slots, int NB, int H, int W, int C, int Ho,
-                                                                   int Wo, int pix_per_block, FastDiv div_w, FastDiv div_h) {
-    __shared__ float red[32][2][64];
-    const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int c = blockIdx.y * 64 + chunk * 8;
-    const bool cok = c < C;
-    float mu[8], rs[8], sc[8], sh[8];
-    if (cok) {
-        load8f(consts + c, mu);
-        load8f(consts + C + c, rs);
-        load8f(consts + 2 * C + c, sc);
-        load8f(consts + 3 * C + c, sh);
-    }
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    const uint32_t npix = static_cast<uint32_t>(NB) * H * W;
-    const uint32_t p0 = blockIdx.x * static_cast<uint32_t>(pix_per_block);
-    const uint32_t p1 = min(npix, p0 + pix_per_block);
-    if (cok) {
-        for (uint32_t pix = p0 + rl; pix < p1; pix += 32) {
-            const uint32_t t = fastdiv(pix, div_w);
-            const int w = static_cast<int>(pix - t * W);
-            const uint32_t n = fastdiv(t, div_h);
-            const int h = static_cast<int>(t - n * H);
-            const bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y + static_cast<size_t>(pix) * C + c));
-            float g[8];
-            maxpool_gather(dout, idx, static_cast<int>(n), h, w, c, C, Ho, Wo, g);
-            bf16x8 zo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float yf = bf16_to_f32(yv[e]);
-                const float d = (yf * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
-                zo[e] = f32_to_bf16(d);
-                s1[e] += d;
-                s2[e] += d * (yf - mu[e]) * rs[e];
-            }
-            if (dz != nullptr) *reinterpret_cast<bf16x8*>(dz + static_cast<size_t>(pix) * C + c) = zo;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        red[rl][0][chunk * 8 + e] = s1[e];
-        red[rl][1][chunk * 8 + e] = s2[e];
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
-        float t = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < 32; ++r) t += red[r][which][col];
-        const int cc = blockIdx.y * 64 + col;
-        if (cc < C) {
-            float* slot = slots + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 3 * C;
-            __hip_atomic_fetch_add(slot + which * C + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// dz may be nullptr: only the sums are produced (pdt_maxpool_bn_bwd_apply forms dz again on the fly).
-PDT_API int pdt_maxpool_bn_bwd_reduce(const void* dout, const void* idx, const void* y, const float* consts, void* dz,
-                                      float* slots, int NB, int H, int W, int C, void* stream) {
-    if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
-    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long long npix = static_cast<long long>(NB) * H * W;
-    if (npix >= (1ll << 31)) return -1;
-    const int ppb = reduce_rows_per_block(static_cast<int>(npix), C);
-    const dim3 g(pdt_cdiv(npix, ppb), pdt_cdiv(C, 64)), b(256);
-    hipLaunchKernelGGL(maxpool_bn_bwd_reduce_kernel, g, b, 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16*>(dout), static_cast<const uint8_t*>(idx), static_cast<const bf16*>(y), consts,
-                       static_cast<bf16*>(dz), slots, NB, H, W, C, Ho, Wo, ppb, make_fastdiv(W), make_fastdiv(H));
-    return pdt_launch_status();
 }
 
 // Second pass: dy = c0*dz + c1*y + c2 with dz gathered from (dout, idx) again.  One thread per (pixel, 8 channels),

@@ -52,8 +52,7 @@ _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i,
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
 _bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 _bn_bwd_apply = _sig("pdt_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
-_bn_relu_maxpool_fwd = _sig("pdt_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
-_maxpool_bn_bwd_reduce = _sig("pdt_maxpool_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
+_bn_relu_maxpool_fwd = _sig("pdt_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _maxpool_bn_bwd_apply = _sig("pdt_maxpool_bn_bwd_apply", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 _avgpool_fwd = _sig("pdt_avgpool_fwd", [_vp, _vp, _i, _i, _i, _vp])
 _avgpool_bwd = _sig("pdt_avgpool_bwd", [_vp, _vp, _i, _i, _i, _vp])
@@ -962,22 +961,26 @@ class _BnReluMaxpool(torch.autograd.Function):
         ho, wo = _conv_out(h, 3, 2, 1), _conv_out(w, 3, 2, 1)
         out = _empty_nhwc(nb, c, ho, wo, y.device)
         idx = torch.empty((nb, ho, wo, c), dtype=torch.uint8, device=y.device)
-        _check(_bn_relu_maxpool_fwd(y.data_ptr(), consts.data_ptr(), out.data_ptr(), idx.data_ptr(), nb, h, w, c,
+        # pre-normalisation value of every window's winner: all that BatchNorm's backward sums need besides dout
+        ywin = torch.empty((nb, ho, wo, c), dtype=torch.bfloat16, device=y.device) if ctx.needs_input_grad[0] else None
+        _check(_bn_relu_maxpool_fwd(y.data_ptr(), consts.data_ptr(), out.data_ptr(), idx.data_ptr(), _ptr(ywin), nb, h, w, c,
                                     _stream()), "bn_relu_maxpool_fwd")
-        ctx.save_for_backward(y, idx, consts, gamma, beta)
+        ctx.save_for_backward(y, idx, consts, gamma, beta, ywin)
         ctx.meta = (count, c, nb, h, w)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, idx, consts, gamma, beta = ctx.saved_tensors
+        y, idx, consts, gamma, beta, ywin = ctx.saved_tensors
         count, c, nb, h, w = ctx.meta
         dout = _as_nhwc(dout)
         dev = y.device
-        # the un-pooled gradient dz is not written out: both passes gather it from (dout, idx), a quarter of y's size
+        # The un-pooled gradient dz is never written out.  Its sums over input pixels equal sums over pooled outputs
+        # taken at the winners (mask recomputed from the winner's value), a pass over two pooled-size tensors; the
+        # apply pass gathers dz from (dout, idx).
         slots = ARENA.alloc((STAT_SLOTS, 3, c), dev)
-        _check(_maxpool_bn_bwd_reduce(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), None,
-                                      slots.data_ptr(), nb, h, w, c, _stream()), "maxpool_bn_bwd_reduce")
+        _check(_bn_bwd_reduce(dout.data_ptr(), None, ywin.data_ptr(), consts.data_ptr(), None, None, slots.data_ptr(),
+                              dout.numel() // c, c, 2, _stream()), "bn_bwd_reduce")
         dgamma, dbeta, coef = _bn_param_grads(slots, 1, count, gamma, beta, consts, c, dev)
         dy = torch.empty_like(y)
         _check(_maxpool_bn_bwd_apply(dout.data_ptr(), idx.data_ptr(), y.data_ptr(), consts.data_ptr(), coef.data_ptr(),
