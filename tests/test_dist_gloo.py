@@ -118,8 +118,8 @@ def test_bench_contract_two_ranks_under_torchrun(free_port):
            "--cpu", "--model", "resnet18", "--image-size", "32", "--batch-size", "4"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]  # stdout carries nothing but the JSON line
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2"
