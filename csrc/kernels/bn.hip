@@ -638,66 +638,87 @@ PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* consts, void* ou
 //   pass 1 (sums):  sum dz and sum dz*xhat over input pixels equal the sums of dout*[z_win > 0] and
 //                   dout*[z_win > 0]*xhat(y_win) over pooled outputs: bn_bwd_reduce on (dout, ywin), both pooled-size
 //   pass 2 (apply): dy = c0*dz + c1*y + c2 with dz gathered from (dout, idx), a quarter of y's size
-__device__ __forceinline__ void maxpool_gather(const bf16* __restrict__ dout, const uint8_t* __restrict__ idx, int n, int h,
-                                               int w, int c, int C, int Ho, int Wo, float (&g)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = 0.f;
-    // windows (oh, ow) that contain (h, w): 2*oh - 1 <= h <= 2*oh + 1
-    const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;
-    const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
-    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-        if (oh >= Ho) continue;
-        const int r = h - (2 * oh - 1);
-        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-            if (ow >= Wo) continue;
-            const int tap = r * 3 + (w - (2 * ow - 1));
-            const size_t o = ((static_cast<size_t>(n) * Ho + oh) * Wo + ow) * C + c;
-            const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
-            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t word = e < 4 ? iv.x : iv.y;
-                const int win = (word >> (8 * (e & 3))) & 0xff;
-                if (win == tap) g[e] += bf16_to_f32(dv[e]);
-            }
-        }
-    }
-}
-
-// Second pass: dy = c0*dz + c1*y + c2 with dz gathered from (dout, idx) again.  One thread per (pixel, 8 channels),
-// consecutive threads on consecutive channel chunks, so a wave reads and writes whole contiguous rows.
+// Second pass: dy = c0*dz + c1*y + c2 with dz gathered from (dout, idx).  A thread owns a 2x2 quad of input pixels
+// (rows 2a, 2a+1; columns 2b, 2b+1) and 8 channels: the quad is covered by the four windows (a + di, b + dj), each
+// loaded once; window (0,0) can have its winner on any of the four pixels (taps 4, 5, 7, 8), window (0,1) on the right
+// column (taps 3, 6), window (1,0) on the lower row (taps 1, 2), window (1,1) on the lower right pixel (tap 0).
+// HOIST: C/8 divides 256, so a thread's channel chunk is the same in every iteration and the constants stay in
+// registers.
+template <bool HOIST>
 __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const bf16* __restrict__ dout,
                                                                   const uint8_t* __restrict__ idx,
                                                                   const bf16* __restrict__ y,
                                                                   const float* __restrict__ consts,
                                                                   const float* __restrict__ coef, bf16* __restrict__ dy,
                                                                   int NB, int H, int W, int C, int Ho, int Wo,
-                                                                  FastDiv div_w, FastDiv div_h, FastDiv div_cvec) {
+                                                                  FastDiv div_wa, FastDiv div_ha, FastDiv div_cvec) {
     const uint32_t cvec = C >> 3;
-    const uint32_t nvec = static_cast<uint32_t>(NB) * H * W * cvec;
-    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < nvec; v += gridDim.x * 256u) {
-        const uint32_t pix = fastdiv(v, div_cvec);
-        const int c = static_cast<int>(v - pix * cvec) << 3;
-        const uint32_t t = fastdiv(pix, div_w);
-        const int w = static_cast<int>(pix - t * W);
-        const uint32_t n = fastdiv(t, div_h);
-        const int h = static_cast<int>(t - n * H);
-        const bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y) + v);
-        float sc[8], sh[8], k0[8], k1[8], k2[8], g[8];
+    const uint32_t Ha = (H + 1) >> 1, Wa = (W + 1) >> 1;
+    const uint32_t nvec = static_cast<uint32_t>(NB) * Ha * Wa * cvec;
+    float sc[8], sh[8], k0[8], k1[8], k2[8];
+    auto load_consts = [&](int c) {
         load8f(consts + 2 * C + c, sc);
         load8f(consts + 3 * C + c, sh);
         load8f(coef + c, k0);
         load8f(coef + C + c, k1);
         load8f(coef + 2 * C + c, k2);
-        maxpool_gather(dout, idx, static_cast<int>(n), h, w, c, C, Ho, Wo, g);
-        bf16x8 o;
+    };
+    if (HOIST) load_consts(static_cast<int>(threadIdx.x & (cvec - 1)) << 3);
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < nvec; v += gridDim.x * 256u) {
+        const uint32_t quad = fastdiv(v, div_cvec);
+        const int c = static_cast<int>(v - quad * cvec) << 3;
+        const uint32_t t = fastdiv(quad, div_wa);
+        const int b = static_cast<int>(quad - t * Wa);
+        const uint32_t n = fastdiv(t, div_ha);
+        const int a = static_cast<int>(t - n * Ha);
+        if (!HOIST) load_consts(c);
+        // the four windows (clamped addresses; a window outside the pooled image contributes nothing)
+        const bool v1 = a + 1 < Ho, w1 = b + 1 < Wo;
+        uint2 iv[4];
+        bf16x8 dv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oh = min(a + (q >> 1), Ho - 1), ow = min(b + (q & 1), Wo - 1);
+            const size_t o = ((static_cast<size_t>(n) * Ho + oh) * Wo + ow) * C + c;
+            iv[q] = *reinterpret_cast<const uint2*>(idx + o);
+            dv[q] = *reinterpret_cast<const bf16x8*>(dout + o);
+        }
+        // the quad's activations (pixels beyond an odd-sized image are skipped)
+        const bool r1 = 2 * a + 1 < H, c1 = 2 * b + 1 < W;
+        const size_t p00 = ((static_cast<size_t>(n) * H + 2 * a) * W + 2 * b) * C + c;
+        const size_t poff[4] = {p00, p00 + C, p00 + static_cast<size_t>(W) * C, p00 + static_cast<size_t>(W) * C + C};
+        const bool pok[4] = {true, c1, r1, r1 && c1};
+        bf16x8 yv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (pok[q]) yv[q] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y + poff[q]));
+        float g[4][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float yf = bf16_to_f32(yv[e]);
-            const float d = (yf * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
-            o[e] = f32_to_bf16(k0[e] * d + k1[e] * yf + k2[e]);
+            auto tap_of = [&](int q) {
+                const uint32_t word = e < 4 ? iv[q].x : iv[q].y;
+                return static_cast<int>((word >> (8 * (e & 3))) & 0xff);
+            };
+            const int t00 = tap_of(0), t01 = w1 ? tap_of(1) : -1, t10 = v1 ? tap_of(2) : -1, t11 = (v1 && w1) ? tap_of(3) : -1;
+            const float d00 = bf16_to_f32(dv[0][e]), d01 = bf16_to_f32(dv[1][e]), d10 = bf16_to_f32(dv[2][e]),
+                        d11 = bf16_to_f32(dv[3][e]);
+            g[0][e] = (t00 == 4 ? d00 : 0.f);
+            g[1][e] = (t00 == 5 ? d00 : 0.f) + (t01 == 3 ? d01 : 0.f);
+            g[2][e] = (t00 == 7 ? d00 : 0.f) + (t10 == 1 ? d10 : 0.f);
+            g[3][e] = (t00 == 8 ? d00 : 0.f) + (t01 == 6 ? d01 : 0.f) + (t10 == 2 ? d10 : 0.f) + (t11 == 0 ? d11 : 0.f);
         }
-        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dy) + v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!pok[q]) continue;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float yf = bf16_to_f32(yv[q][e]);
+                const float d = (yf * sc[e] + sh[e]) > 0.f ? g[q][e] : 0.f;
+                o[e] = f32_to_bf16(k0[e] * d + k1[e] * yf + k2[e]);
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dy + poff[q]));
+        }
     }
 }
 
@@ -705,14 +726,17 @@ PDT_API int pdt_maxpool_bn_bwd_apply(const void* dout, const void* idx, const vo
                                      const float* coef, void* dy, int NB, int H, int W, int C, void* stream) {
     if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long long nvec = static_cast<long long>(NB) * H * W * (C / 8);
-    if (nvec >= (1ll << 31)) return -1;
+    const int Ha = (H + 1) / 2, Wa = (W + 1) / 2, cvec = C / 8;
+    if (static_cast<long long>(NB) * H * W * cvec >= (1ll << 31)) return -1;
+    const long long nvec = static_cast<long long>(NB) * Ha * Wa * cvec;
     long long grid = (nvec + 255) / 256;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel, dim3(static_cast<int>(grid)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(dout), static_cast<const uint8_t*>(idx),
-                       static_cast<const bf16*>(y), consts, coef, static_cast<bf16*>(dy), NB, H, W, C, Ho, Wo,
-                       make_fastdiv(W), make_fastdiv(H), make_fastdiv(C / 8));
+    const bool hoist = cvec <= 256 && (cvec & (cvec - 1)) == 0;
+    auto kernel = hoist ? maxpool_bn_bwd_apply_kernel<true> : maxpool_bn_bwd_apply_kernel<false>;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<int>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(dout), static_cast<const uint8_t*>(idx), static_cast<const bf16*>(y), consts,
+                       coef, static_cast<bf16*>(dy), NB, H, W, C, Ho, Wo, make_fastdiv(Wa), make_fastdiv(Ha),
+                       make_fastdiv(cvec));
     return pdt_launch_status();
 }
 

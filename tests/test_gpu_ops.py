@@ -227,17 +227,20 @@ def test_bn_eval_uses_running_stats(hip):
     assert _rel_err(out, ref) < 1e-2
 
 
-def test_stem_tail_maxpool(hip):
+@pytest.mark.parametrize("c,h,w", [(64, 30, 30), (64, 29, 31), (24, 17, 16), (128, 9, 9)])
+def test_stem_tail_maxpool(hip, c, h, w):
+    """BN + ReLU + 3x3/2 max-pool, forward and backward (sums from pooled-size tensors, quad-wise gather), on even
+    and odd image sizes and with a channel count whose per-thread constants cannot be hoisted (24)."""
     torch.manual_seed(3)
     dev = _dev()
-    conv = nn.Conv2d(64, 64, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
-    x = hip.to_device_layout(torch.randn(4, 64, 30, 30, device=dev))
-    bn = nn.BatchNorm2d(64).to(dev)
+    conv = nn.Conv2d(64, c, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    x = hip.to_device_layout(torch.randn(4, 64, h, w, device=dev))
+    bn = nn.BatchNorm2d(c).to(dev)
     y, st = hip.conv2d_stats(x, conv.weight, 1, 0)
     y = y.detach().requires_grad_(True)
     out = hip.bn_relu_maxpool(y, st, bn)
     yr = y.detach().float().requires_grad_(True)
-    rbn = nn.BatchNorm2d(64).to(dev)
+    rbn = nn.BatchNorm2d(c).to(dev)
     ref = F.max_pool2d(F.relu(_ref_bn(yr, rbn)), 3, 2, 1)
     assert out.shape == ref.shape
     assert _rel_err(out, ref) < 1e-2
