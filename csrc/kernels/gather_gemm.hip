@@ -59,6 +59,7 @@ struct GatherGemmArgs {
     FastDiv div_ab;  // divide by OA*OB
     FastDiv div_b;   // divide by OB
     int tw;          // packed-row mode: elements per kernel row (32 or 64)
+    int cs;          // elements between consecutive input pixels (C, except in the ring kernels' packed-row mode)
     int OA, OB;
     int tap_dh[GG_MAX_TAPS];
     int tap_dw[GG_MAX_TAPS];
@@ -411,6 +412,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     auto swz = [](int row) { return BK == 64 ? (row & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3); };
     const int lrow = lane / CPR;                              // row of this lane inside a DMA piece
     const int kchunk = ((lane % CPR) ^ swz(lrow)) << 3;       // swizzled source chunk (pieces start at multiples of 16 rows)
+    // Offset of this lane's chunk inside an activation row.  Packed rows (few input channels, see gather_gemm_kernel):
+    // a K-step of 64 spans 64 / tw kernel rows of tw contiguous elements each, so chunk j lies (j / (tw/8)) image rows
+    // further down; a "tap" is then one K-step (dh = its first kernel row) and C = 64 makes it a single channel block.
+    const int kchunk_a = p.tw ? ((kchunk >> 3) / (p.tw >> 3)) * p.Win * p.cs + (((kchunk >> 3) % (p.tw >> 3)) << 3) : kchunk;
     int ld_tile = first, ld_t = 0, ld_c0 = 0, ld_issued = 0, ld_slot = 0;
     int a_pix[AI], a_h[AI], a_w[AI];
     int b_off[BI];
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             const int ih = a_h[i] + dh, iw = a_w[i] + dw;
             const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
                             static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
-            const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.C + ld_c0 + kchunk;
+            const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.cs + ld_c0 + kchunk_a;
             const bf16* src = ok ? p.A + off : p.zeros;
             __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + (wave * AI + i) * PR * BK), 16, 0, 0);
         }
@@ -919,6 +924,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.div_ab = make_fastdiv(static_cast<uint32_t>(OA) * OB);
     a.div_b = make_fastdiv(OB);
     a.tw = smallc;
+    a.cs = C;
     for (int t = 0; t < T; ++t) {
         if (!smallc && (tap_woff[t] % 8) != 0) return -1;
         a.tap_dh[t] = tap_dh[t];
@@ -926,7 +932,21 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (smallc) return N <= 64 ? launch_gather_gemm<128, 64, 4, 1, true>(a, s) : launch_gather_gemm<128, 128, 2, 2, true>(a, s);
+    if (smallc && tile >= 13 && zeros != nullptr) {
+        // packed rows on the ring kernels: one "tap" per K-step of 64 / tw kernel rows, a single 64-wide channel block.
+        // The last K-step may reach one image row past the kernel (zero weights there): the caller keeps one readable
+        // row behind the last image.
+        const int rows_per_step = GG_BK / smallc, steps = (T * smallc + GG_BK - 1) / GG_BK;
+        a.T = steps;
+        a.C = GG_BK;
+        for (int t = 0; t < steps; ++t) {
+            a.tap_dh[t] = t * rows_per_step;
+            a.tap_dw[t] = 0;
+            a.tap_woff[t] = t * GG_BK;
+        }
+    } else if (smallc) {
+        return N <= 64 ? launch_gather_gemm<128, 64, 4, 1, true>(a, s) : launch_gather_gemm<128, 128, 2, 2, true>(a, s);
+    }
     switch (tile) {
         case 0: return launch_gather_gemm<128, 128, 2, 2>(a, s);
         case 1: return launch_gather_gemm<128, 64, 4, 1>(a, s);

@@ -684,8 +684,12 @@ class _ConvStats(torch.autograd.Function):
             if c > 8 or tw > 64 or r > 49:
                 raise NotImplementedError("few-channel convolution: needs Cin <= 8 and a kernel row of at most 64 elements")
             hp, wp = (ho - 1) * stride + r, (wo - 1) * stride + tw // cp
-            xp = torch.empty((nb, hp, wp, cp), dtype=torch.bfloat16, device=x.device)
-            _check_size(xp)
+            # one more (zeroed) image row behind the last image: the ring kernel's last K-step addresses the kernel row
+            # after the last one (its weights are zero, but the address must be readable and hold finite values)
+            xp_rows = torch.empty((nb * hp + 1, wp, cp), dtype=torch.bfloat16, device=x.device)
+            xp_rows[-1].zero_()
+            xp = xp_rows[: nb * hp].view(nb, hp, wp, cp)
+            _check_size(xp_rows)
             _check(_pad_pixels(x.data_ptr(), xp.data_ptr(), nb, h, w_, c, cp, hp, wp, padding, _stream()), "pad_pixels")
             kpad = _round_up(r * tw, 64)
             wb = _packed_rows_weight(weight, cp, tw, kpad)

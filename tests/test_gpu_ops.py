@@ -95,6 +95,9 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
     monkeypatch.setattr(hip, "_TILE_NARROW", tile)
     test_conv_forward_backward(hip, 9, 64, 64, 3, 1, 1, 37)
     test_conv_forward_backward(hip, 6, 256, 64, 1, 1, 0, 56)
+    # the 3-channel stem ("packed rows": a K-step spans two kernel rows), odd size so the last tile is partial and the
+    # last image's last output row reaches the spare row behind the padded input
+    test_conv_forward_backward(hip, 3, 3, 64, 7, 2, 3, 61)
 
 
 @pytest.mark.parametrize("tile", [13, 16])
