@@ -664,26 +664,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             stats_n0 = n0;
         }
         const int ncol = n0 + wn * TN + ech * 8;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            // output pixels of this lane's rows in the 16-row group, and (BatchNorm-backward sums) the loads of the
-            // matching activations, issued first so their latency hides behind the staging round trip below
-            constexpr int NPS = 16 / RPP;
-            size_t pixo[NPS];
-            bool rok[NPS];
-            bf16x8 yv[NPS], av[NPS], y2v[NPS];
-            unsigned amb[NPS];
+        // Output pixels of this lane's rows in a 16-row group and the loads of the epilogue operands that share the
+        // output's layout (shortcut gradient, BatchNorm inputs, pre-activation).  Two register sets: the operands of
+        // group i + 1 are requested before group i is staged and processed, so their latency is covered by a whole
+        // group's work instead of one LDS round trip.
+        constexpr int NPS = 16 / RPP;
+        size_t pixo_[2][NPS];
+        bool rok_[2][NPS];
+        bf16x8 yv_[2][NPS], av_[2][NPS], y2v_[2][NPS];
+        unsigned amb_[2][NPS], bnb_[2][NPS];
+        auto fetch = [&](int i, int st) {
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
                 const int m = m0 + wm * TM + i * 16 + ps * RPP + erow;
-                rok[ps] = m < p.M && ncol < p.N;
+                rok_[st][ps] = m < p.M && ncol < p.N;
                 const int mc = min(m, p.M - 1);
                 const uint32_t img = fastdiv(mc, p.div_ab);
                 const uint32_t rem = mc - img * (p.OA * p.OB);
                 const uint32_t a = fastdiv(rem, p.div_b);
                 const uint32_t b = rem - a * p.OB;
-                pixo[ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
-                           min(ncol, p.N - 8);
+                pixo_[st][ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
+                                min(ncol, p.N - 8);
                 // operands with the layout of the output are read once: streamed past the caches when they are large
                 auto ld8 = [&](const bf16* q) {
                     bf16x8 r;
@@ -696,14 +697,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                     }
                     return r;
                 };
-                if (EPI & 12) yv[ps] = ld8(p.bn_y + pixo[ps]);
-                if (EPI & 64) y2v[ps] = ld8(p.bn_y2 + pixo[ps]);
-                if (EPI & 16) yv[ps] = ld8(p.act_src + pixo[ps]);
+                if (EPI & 12) yv_[st][ps] = ld8(p.bn_y + pixo_[st][ps]);
+                if (EPI & 64) y2v_[st][ps] = ld8(p.bn_y2 + pixo_[st][ps]);
+                if (EPI & 16) yv_[st][ps] = ld8(p.act_src + pixo_[st][ps]);
+                if (EPI & 8) bnb_[st][ps] = p.bn_bits[pixo_[st][ps] >> 3];
                 if (EPI & 2) {
-                    av[ps] = ld8(p.addend + pixo[ps]);
-                    amb[ps] = p.addend_bits != nullptr ? p.addend_bits[pixo[ps] >> 3] : 0xffu;
+                    av_[st][ps] = ld8(p.addend + pixo_[st][ps]);
+                    amb_[st][ps] = p.addend_bits != nullptr ? p.addend_bits[pixo_[st][ps] >> 3] : 0xffu;
                 }
             }
+        };
+        constexpr bool AHEAD = (EPI & 64) == 0;  // three operand tensors in two sets do not fit the register file
+        if (AHEAD) fetch(0, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if (!AHEAD) fetch(i, i & 1);
+            else if (i + 1 < FM) fetch(i + 1, (i + 1) & 1);
+            size_t(&pixo)[NPS] = pixo_[i & 1];
+            bool(&rok)[NPS] = rok_[i & 1];
+            bf16x8(&yv)[NPS] = yv_[i & 1];
+            bf16x8(&av)[NPS] = av_[i & 1];
+            bf16x8(&y2v)[NPS] = y2v_[i & 1];
+            unsigned(&amb)[NPS] = amb_[i & 1];
+            unsigned(&bnb)[NPS] = bnb_[i & 1];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int nl = j * 16 + (lane >> 4) * 4;
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                         *reinterpret_cast<f32x4*>(rs + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + p.N + ncol + 4);
                         unsigned mb = 0xffu;
                         if (EPI & 8) {
-                            mb = p.bn_bits[o >> 3];
+                            mb = bnb[ps];  // requested with the other operands: a load here would be waited for on the spot
                         } else {
                             float sc[8], sh[8];
                             *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + ncol);
