@@ -669,10 +669,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         // group i + 1 are requested before group i is staged and processed, so their latency is covered by a whole
         // group's work instead of one LDS round trip.
         constexpr int NPS = 16 / RPP;
-        size_t pixo_[2][NPS];
-        bool rok_[2][NPS];
-        bf16x8 yv_[2][NPS], av_[2][NPS], y2v_[2][NPS];
-        unsigned amb_[2][NPS], bnb_[2][NPS];
+        size_t pixo_[3][NPS];
+        bool rok_[3][NPS];
+        bf16x8 yv_[3][NPS], av_[3][NPS], y2v_[3][NPS];
+        unsigned amb_[3][NPS], bnb_[3][NPS];
         auto fetch = [&](int i, int st) {
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
@@ -707,19 +707,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 }
             }
         };
-        constexpr bool AHEAD = (EPI & 64) == 0;  // three operand tensors in two sets do not fit the register file
-        if (AHEAD) fetch(0, 0);
+        // Groups requested ahead (group g lives in register set g % 3): none with three operand tensors (they do not fit
+        // the register file twice), one for the tiles whose accumulators fill half the registers, two for the smaller tiles.
+        constexpr int AHEAD = (EPI & 64) ? 0 : (FM * FN <= 16 ? 2 : 1);
+#pragma unroll
+        for (int g = 0; g < AHEAD && g < FM; ++g) fetch(g, g % 3);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            if (!AHEAD) fetch(i, i & 1);
-            else if (i + 1 < FM) fetch(i + 1, (i + 1) & 1);
-            size_t(&pixo)[NPS] = pixo_[i & 1];
-            bool(&rok)[NPS] = rok_[i & 1];
-            bf16x8(&yv)[NPS] = yv_[i & 1];
-            bf16x8(&av)[NPS] = av_[i & 1];
-            bf16x8(&y2v)[NPS] = y2v_[i & 1];
-            unsigned(&amb)[NPS] = amb_[i & 1];
-            unsigned(&bnb)[NPS] = bnb_[i & 1];
+            if (i + AHEAD < FM) fetch(i + AHEAD, (i + AHEAD) % 3);
+            size_t(&pixo)[NPS] = pixo_[i % 3];
+            bool(&rok)[NPS] = rok_[i % 3];
+            bf16x8(&yv)[NPS] = yv_[i % 3];
+            bf16x8(&av)[NPS] = av_[i % 3];
+            bf16x8(&y2v)[NPS] = y2v_[i % 3];
+            unsigned(&amb)[NPS] = amb_[i % 3];
+            unsigned(&bnb)[NPS] = bnb_[i % 3];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int nl = j * 16 + (lane >> 4) * 4;
