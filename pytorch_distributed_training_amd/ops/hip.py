@@ -407,6 +407,11 @@ SHADOWS = ShadowCache()
 _TILE_WIDE = int(_os.environ.get("PDT_GEMM_TILE_WIDE", "-1"))  # -1: choose per shape
 _TILE_NARROW = int(_os.environ.get("PDT_GEMM_TILE_NARROW", "-1"))  # -1: choose per shape
 _RING_MIN_TILES = int(_os.environ.get("PDT_GEMM_RING_MIN_TILES", "768"))
+# Data-gradient launches that also add a shortcut gradient and take a block tail's BatchNorm sums stream four tensors
+# through the epilogue; with the 256x256 tile's accumulators there is no register room to keep enough of those loads in
+# flight, so they run on the 256x128 tile (two groups of operands requested ahead): -1.1 ms per ResNet-50 step.  (The
+# launches that only take sums with a recomputed mask are faster on the 256x256 tile.)
+_TILE_FUSED_TAIL = int(_os.environ.get("PDT_GEMM_TILE_FUSED_TAIL", "13"))
 
 
 _ZERO_PAGES: dict = {}
@@ -480,11 +485,14 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
         if len(bn_stat) == 5:  # a second BatchNorm shares dz (projected shortcut): its sums go to the third row
             bn_y2, bn_consts2 = bn_stat[3:]
     dh, dw, wo = _tap_arrays(taps)
+    tile = _pick_tile(M, N, len(taps) * max(C // 64, 1))
+    if _TILE_FUSED_TAIL >= 0 and bn_bits is not None and tile == 16:
+        tile = _TILE_FUSED_TAIL
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo,
-                     _pick_tile(M, N, len(taps) * max(C // 64, 1)), int(smallc),
+                     tile, int(smallc),
                      _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _ptr(bn_y2), _ptr(bn_consts2),
                      1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _stream()),
         "gather_gemm",
