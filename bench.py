@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +38,12 @@ def parse_args():
     ap.add_argument("--seq-len", type=int, default=1024)
     ap.add_argument("--optimizer", type=str, default="")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--last-bucket-mb", type=float, default=1.0)
+    ap.add_argument("--grad-dtype", type=str, default="fp32", choices=["fp32", "bf16"],
+                    help="element type of gradients on the wire (accumulation inside a rank stays fp32)")
+    ap.add_argument("--reduce-algorithm", type=str, default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--extras-timeout-s", type=float, default=120.0,
+                    help="the untimed diagnostics after the measurement are abandoned after this long")
     ap.add_argument("--cpu", action="store_true", help="plumbing check on CPU/gloo (not a valid benchmark)")
     ap.add_argument("--no-dp", action="store_true", help="single process: skip the one-rank data-parallel wrap")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed diagnostics after the timed steps")
@@ -79,11 +86,7 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        try:
-            env = init_distributed(True, use_cpu=False)
-        except Exception as e:  # no usable process group on this box: time the unwrapped model
-            print(f"warning: one-rank process group unavailable ({e}); running without the reducer", file=sys.stderr)
-            env = init_distributed(False, use_cpu=False)
+        env = init_distributed(True, use_cpu=False)
     else:
         env = init_distributed(world > 1, use_cpu=args.cpu)
     if env.world_size != args.gpus and env.is_main:
@@ -98,7 +101,8 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     raw = ops.prepare_module(model)
     if env.distributed:
-        model = wrap_data_parallel(model, env, bucket_mb=args.bucket_mb)
+        model = wrap_data_parallel(model, env, bucket_mb=args.bucket_mb, grad_dtype=args.grad_dtype,
+                                   algorithm=args.reduce_algorithm, last_bucket_mb=args.last_bucket_mb)
     opt_name = args.optimizer or ("adamw" if (is_lm or args.model.startswith("vit")) else "sgd")
     lr = 3e-4 if opt_name != "sgd" else 0.1
     wd = 0.1 if opt_name == "adamw" else 1e-4
@@ -165,84 +169,155 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
 
-    # Untimed diagnostics (every rank takes part): the same step with the gradient all-reduce switched off, and
-    # the all-reduce rate of the reducer's communicator over message sizes.  They tell how much of the collective
-    # is hidden behind backward and what the links deliver; the headline number above is not affected.
-    extras = {}
-    if env.distributed and on_gpu and not args.no_extras:
-        try:
-            n_local = max(2, min(5, args.steps))
-            with model.no_sync():
-                step(0)
-                sync()
-                t1 = time.perf_counter()
-                for i in range(n_local):
-                    step(i)
-                sync()
-                local_ms = 1e3 * (time.perf_counter() - t1) / n_local
-            zero_grad()
-            extras["ms_per_step_without_allreduce"] = round(local_ms, 3)
-            extras["allreduce_exposed_ms"] = round(1e3 * elapsed / args.steps - local_ms, 3)
-            extras["buckets"] = model.reducer.bucket_summary()
-            extras["transport"] = type(model.transport).__name__
-            comm = getattr(model.transport, "comm", None)
-            if comm is not None and env.world_size > 1:
-                sweep = {}
-                for mib in (1, 4, 16, 64, 256):
-                    buf = torch.zeros(mib * 262144, dtype=torch.float32, device=dev)
-                    us = comm.time_all_reduce(buf, warmup=3, iters=10)
-                    alg = mib * 1048576 / us / 1e3  # GB/s
-                    sweep[f"{mib}MiB"] = {"us": round(us, 1), "algbw_GBps": round(alg, 1),
-                                          "busbw_GBps": round(alg * 2 * (env.world_size - 1) / env.world_size, 1)}
-                    del buf
-                extras["allreduce_sweep_fp32"] = sweep
-        except Exception as e:  # diagnostics must never cost the measurement
-            extras["error"] = repr(e)
-
     per_step_samples = args.batch_size * env.world_size
     unit_scale = args.seq_len if is_lm else 1
     value = per_step_samples * unit_scale * args.steps / elapsed
-    if env.is_main:
-        out = {
-            "metric": ("tokens/sec (whole job) " if is_lm else "images/sec (whole node) ")
-            + f"{args.model} {'seq ' + str(args.seq_len) if is_lm else str(args.image_size) + '^2'} "
-            + f"{'bf16' if on_gpu else 'fp32'} training",
-            "value": round(value, 2),
-            "unit": "tokens/s" if is_lm else "images/s",
-            "n_gpus": env.world_size,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "setup_steps": 2,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16" if on_gpu else "fp32",
-            "data": "synthetic (device-resident random batches, random-init weights)",
-            "config": {
-                "model": args.model,
-                "global_batch": per_step_samples,
-                "per_gpu_batch": args.batch_size,
-                "seq_len": args.seq_len if is_lm else None,
-                "image_size": None if is_lm else args.image_size,
-                "optimizer": opt_name,
-                "parallelism": f"dp{env.world_size}",
-                "bucket_mb": args.bucket_mb,
-            },
-            "final_loss": round(final_loss, 4),
-            "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1) if on_gpu else None,
-        }
-        # the reference publishes no number (vs_baseline stays null); the same model on stock PyTorch-ROCm
-        # (bench/stock_baseline.py, 1x MI355X, the best of its measured batch sizes) is the self-measured yardstick
-        stock = {"resnet50": 6510.2, "vit_b_16": 3688.0, "gpt2_medium": 194240.0}.get(args.model)
-        if stock and on_gpu:
-            out["vs_stock_pytorch_rocm_per_gpu"] = round(value / (stock * env.world_size), 3)
-        if extras:
-            out["extras"] = extras
-        print(json.dumps(out), file=result_out, flush=True)
+    out = {
+        "metric": ("tokens/sec (whole job) " if is_lm else "images/sec (whole node) ")
+        + f"{args.model} {'seq ' + str(args.seq_len) if is_lm else str(args.image_size) + '^2'} "
+        + f"{'bf16' if on_gpu else 'fp32'} training",
+        "value": round(value, 2),
+        "unit": "tokens/s" if is_lm else "images/s",
+        "n_gpus": env.world_size,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "setup_steps": 2,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16" if on_gpu else "fp32",
+        "data": "synthetic (device-resident random batches, random-init weights)",
+        "config": {
+            "model": args.model,
+            "global_batch": per_step_samples,
+            "per_gpu_batch": args.batch_size,
+            "seq_len": args.seq_len if is_lm else None,
+            "image_size": None if is_lm else args.image_size,
+            "optimizer": opt_name,
+            "parallelism": f"dp{env.world_size}",
+            "bucket_mb": args.bucket_mb,
+            "grad_dtype": args.grad_dtype,
+            "reduce_algorithm": args.reduce_algorithm,
+        },
+        "final_loss": round(final_loss, 4),
+        "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1) if on_gpu else None,
+    }
+    # the reference publishes no number (vs_baseline stays null); the same model on stock PyTorch-ROCm
+    # (bench/stock_baseline.py, 1x MI355X, the best of its measured batch sizes) is the self-measured yardstick
+    stock = STOCK_PER_GPU.get(args.model)
+    if stock and on_gpu:
+        out["vs_stock_pytorch_rocm_per_gpu"] = round(value / (stock * env.world_size), 3)
+
+    printed = threading.Lock()
+
+    def emit(extras_now):
+        """Rank 0 prints the one JSON line (exactly once, whoever gets here first)."""
+        if not printed.acquire(blocking=False):
+            return
+        if env.is_main:
+            rec = dict(out)
+            if extras_now:
+                rec["extras"] = dict(extras_now)
+            print(json.dumps(rec), file=result_out, flush=True)
+
+    # Untimed checks and diagnostics (every rank takes part).  They prove that the timed steps were a real N-rank
+    # job - RCCL's own rank count, a rank-sum through the reducer's communicator, bit-identical parameters on every
+    # rank afterwards - and tell how much of the collective is hidden behind backward, what the links deliver and
+    # how the bucket size matters.  The headline number above is not affected, and a diagnostic that hangs cannot
+    # take it away: after --extras-timeout-s the line is printed with what has been collected and the process ends.
+    extras = {}
+
+    def give_up():
+        extras["error"] = f"diagnostics abandoned after {args.extras_timeout_s:.0f} s"
+        emit(extras)
+        os._exit(0)
+
+    guard = threading.Timer(args.extras_timeout_s, give_up)
+    guard.daemon = True
+    if env.distributed and not args.no_extras:
+        guard.start()
+        try:
+            collect_extras(extras, args, env, model, raw, step, sync, zero_grad, elapsed, on_gpu, dev)
+        except Exception as e:  # diagnostics must never cost the measurement
+            extras["error"] = repr(e)
+    guard.cancel()
+    emit(extras)
     if env.distributed:
         model.reducer.close()
     shutdown(env)
+
+
+STOCK_PER_GPU = {"resnet50": 6510.2, "vit_b_16": 3688.0, "gpt2_medium": 194240.0}
+
+
+def collect_extras(extras, args, env, model, raw, step, sync, zero_grad, elapsed, on_gpu, dev):
+    reducer = model.reducer
+    extras["buckets"] = reducer.bucket_summary()
+    extras["transport"] = type(model.transport).__name__
+    extras["wire_mib_per_step"] = round(reducer.wire_bytes_per_step / 2**20, 1)
+    comm = getattr(model.transport, "comm", None)
+    # --- proofs of an N-rank job
+    if comm is not None:
+        extras["rccl_ranks"] = comm.rccl_ranks  # ncclCommCount of the reducer's communicator
+        t = torch.full((4,), float(env.rank + 1), device=dev)
+        comm.ordered_all_reduce_(t, "sum")
+        got = float(t[0])
+        extras["rank_sum"] = {"got": got, "expected": env.world_size * (env.world_size + 1) / 2}
+        sums = torch.stack([p.detach().sum() for p in raw.parameters()]
+                           + [p.detach().abs().sum() for p in raw.parameters()]).float()
+        spread = torch.cat([sums, -sums])
+        comm.ordered_all_reduce_(spread, "max")  # max(v) + max(-v) = max(v) - min(v) over ranks
+        n = sums.numel()
+        delta = float((spread[:n] + spread[n:]).abs().max())
+        extras["params_max_abs_delta_across_ranks"] = delta
+        extras["params_in_sync"] = bool(delta == 0.0 and got == extras["rank_sum"]["expected"]
+                                        and extras["rccl_ranks"] == env.world_size)
+    else:
+        flat = torch.cat([p.detach().reshape(-1) for p in raw.parameters()])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1.0 if torch.equal(ref, flat) else 0.0])
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        extras["params_in_sync"] = bool(float(same) == 1.0)
+    # --- the same step with the gradient collectives switched off
+    n_local = max(2, min(5, args.steps))
+
+    def time_steps(n):
+        step(0)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(n):
+            step(i)
+        sync()
+        return 1e3 * (time.perf_counter() - t1) / n
+
+    with model.no_sync():
+        local_ms = time_steps(n_local)
+    zero_grad()
+    extras["ms_per_step_without_allreduce"] = round(local_ms, 3)
+    extras["allreduce_exposed_ms"] = round(1e3 * elapsed / args.steps - local_ms, 3)
+    if comm is not None and env.world_size > 1:
+        # --- what the links deliver: all-reduce rate of the reducer's communicator over message sizes
+        for name, dtype, per_mib in (("fp32", torch.float32, 262144), ("bf16", torch.bfloat16, 524288)):
+            sweep = {}
+            for mib in (1, 4, 16, 64, 256):
+                buf = torch.zeros(mib * per_mib, dtype=dtype, device=dev)
+                us = comm.time_all_reduce(buf, warmup=3, iters=10)
+                alg = mib * 1048576 / us / 1e3  # GB/s
+                sweep[f"{mib}MiB"] = {"us": round(us, 1), "algbw_GBps": round(alg, 1),
+                                      "busbw_GBps": round(alg * 2 * (env.world_size - 1) / env.world_size, 1)}
+                del buf
+            extras[f"allreduce_sweep_{name}"] = sweep
+        # --- how the bucket capacity matters for this model on this node (3 timed steps each, same step function)
+        tuning = {}
+        for mb in (8, 16, 25, 50, 100):
+            reducer.rebucket(mb)
+            zero_grad()
+            tuning[f"{mb}MiB"] = {"ms_per_step": round(time_steps(3), 3), "buckets": len(reducer.buckets)}
+        extras["bucket_mb_sweep"] = tuning
+        reducer.rebucket(args.bucket_mb)
+        zero_grad()
 
 
 if __name__ == "__main__":

@@ -30,10 +30,10 @@ struct PdtReducer {
     std::mutex mu;  // autograd may call hooks from several threads
 
     // Launch every consecutive ready bucket starting at next_launch.
-    int drain() {
+    int drain(void* stream) {
         int n = 0;
         while (next_launch < n_buckets && bucket_pending[next_launch] == 0) {
-            launch(user, next_launch);
+            launch(user, next_launch, stream);
             launched[next_launch] = 1;
             ++next_launch;
             ++launches;
@@ -54,24 +54,40 @@ struct PdtReducer {
 extern "C" {
 
 int pdt_plan_buckets(const int64_t* numel, const int32_t* elem_size, int n, const int32_t* order,
-                     int64_t first_cap_bytes, int64_t cap_bytes, int64_t align_bytes,
+                     int64_t first_cap_bytes, int64_t cap_bytes, int64_t last_cap_bytes, int64_t align_bytes,
                      int32_t* bucket_of, int64_t* offset_bytes, int64_t* bucket_bytes) {
     if (n <= 0) return 0;
     if (cap_bytes <= 0) cap_bytes = INT64_MAX;
     if (first_cap_bytes <= 0) first_cap_bytes = cap_bytes;
+    auto param_at = [&](int k) { return order ? order[k] : n - 1 - k; };
+    // Parameters from position `tail_from` of the visiting order on form the final bucket: the longest suffix of
+    // one element size that fits the final capacity (never the whole list, never an empty suffix).
+    int tail_from = n;
+    if (last_cap_bytes > 0 && n > 1) {
+        int64_t fill = 0;
+        const int32_t es = elem_size[param_at(n - 1)];
+        for (int k = n - 1; k >= 1; --k) {
+            const int p = param_at(k);
+            const int64_t bytes = round_up(numel[p] * elem_size[p], align_bytes);
+            if (elem_size[p] != es || (fill > 0 && fill + bytes > last_cap_bytes)) break;
+            if (fill == 0 && bytes > last_cap_bytes) break;  // a single large tensor: leave it where it falls
+            fill += bytes;
+            tail_from = k;
+        }
+    }
     int bucket = -1;
     int64_t fill = 0;
     int32_t cur_elem = 0;
     for (int k = 0; k < n; ++k) {
-        const int p = order ? order[k] : n - 1 - k;
+        const int p = param_at(k);
         const int64_t bytes = numel[p] * elem_size[p];
         const int64_t cap = (bucket <= 0) ? first_cap_bytes : cap_bytes;
         const int64_t start = round_up(fill, align_bytes);
-        const bool fits = bucket >= 0 && cur_elem == elem_size[p] && (fill == 0 || start + bytes <= cap);
+        const bool fits = bucket >= 0 && k != tail_from && cur_elem == elem_size[p] &&
+                          (fill == 0 || k > tail_from || start + bytes <= cap);
         if (!fits) {
             if (bucket >= 0) bucket_bytes[bucket] = round_up(fill, align_bytes);
             ++bucket;
-            fill = 0;
             cur_elem = elem_size[p];
             bucket_of[p] = bucket;
             offset_bytes[p] = 0;
@@ -115,16 +131,16 @@ void pdt_reducer_prepare(PdtReducer* r) {
     r->reset();
 }
 
-int pdt_reducer_mark_ready(PdtReducer* r, int param) {
+int pdt_reducer_mark_ready(PdtReducer* r, int param, void* stream) {
     std::lock_guard<std::mutex> g(r->mu);
     if (param < 0 || param >= r->n_params || r->marked[param]) return -1;
     r->marked[param] = 1;
     r->ready_order.push_back(param);
     r->bucket_pending[r->bucket_of[param]]--;
-    return r->drain();
+    return r->drain(stream);
 }
 
-int pdt_reducer_finalize(PdtReducer* r) {
+int pdt_reducer_finalize(PdtReducer* r, void* stream) {
     std::lock_guard<std::mutex> g(r->mu);
     int unused = 0;
     for (int p = r->n_params - 1; p >= 0; --p) {
@@ -135,8 +151,8 @@ int pdt_reducer_finalize(PdtReducer* r) {
             ++unused;
         }
     }
-    r->drain();
-    for (int b = 0; b < r->n_buckets; ++b) r->wait(r->user, b);
+    r->drain(stream);
+    for (int b = 0; b < r->n_buckets; ++b) r->wait(r->user, b, stream);
     r->last_order = r->ready_order;
     return unused;
 }

@@ -1,25 +1,41 @@
 // RCCL transport for the gradient-bucket reducer.
 //
 // One communicator per process (one process per GPU).  All collectives are issued on a
-// dedicated, high-priority HIP stream owned by this file; ordering against the compute
-// stream is expressed only with HIP events, so backward kernels and bucket all-reduces
-// overlap:
+// dedicated, high-priority HIP stream owned by this file; ordering against the stream the
+// training step runs on is expressed only with HIP events, so backward kernels and bucket
+// collectives overlap:
 //
-//   compute stream:  ... wgrad(bucket k complete) --record(ready[k])--> ... more backward ...
-//   comm stream:     wait(ready[k]) -> ncclAllReduce(bucket k) -> record(done[k])
-//   compute stream:  (end of backward) wait(done[0..n)) -> optimizer kernel
+//   step stream:  ... wgrad(bucket k complete) --record(ready[k])--> ... more backward ...
+//   comm stream:  wait(ready[k]) -> [pack] -> collective(bucket k) -> [unpack] -> record(done[k])
+//   step stream:  (end of backward) wait(done[0..n)) -> optimizer kernel
+//
+// The step stream is an argument of every launch / wait call (the stream current on the calling
+// thread), never a stored handle: inside a hipGraph capture the event record lands on the capturing
+// stream, the wait pulls the communication stream into the capture, and the collective becomes a
+// node of the graph that every replay executes.
+//
+// Per bucket the collective is one of
+//   * ncclAllReduce in place (ncclAvg), or
+//   * ncclReduceScatter + ncclAllGather in place (each rank owns 1/world of the bucket between the
+//     two calls) - the two-phase direct form a fully connected xGMI node favours,
+// on the bucket's own element type or, for fp32 buckets, on a bf16 wire copy: a pack kernel casts
+// and divides by the world size, the collective sums in bf16, an unpack kernel writes the fp32
+// gradients back.  Half the bytes cross the links; accumulation inside a rank stays fp32.
 //
 // The unique id is created on rank 0 (pdt_rccl_unique_id) and distributed by the caller
 // through whatever key-value store it already has (torch's TCPStore in this repository).
 //
 // Role parity: c10d ProcessGroupNCCL + Reducer as reached from
 // /root/reference/src/main.py:39-41,53,78.
+#include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,17 +43,25 @@
 
 namespace {
 
-thread_local std::string g_last_error;
+// Last error text, process-wide: bucket launches run on autograd's device thread while the error is
+// usually read from the main thread.
+std::mutex g_err_mu;
+std::string g_last_error;
+
+void set_error(const std::string& s) {
+    std::lock_guard<std::mutex> g(g_err_mu);
+    g_last_error = s;
+}
 
 bool hip_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
-    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
     return false;
 }
 
 bool nccl_ok(ncclResult_t e, const char* what) {
     if (e == ncclSuccess) return true;
-    g_last_error = std::string(what) + ": " + ncclGetErrorString(e);
+    set_error(std::string(what) + ": " + ncclGetErrorString(e));
     return false;
 }
 
@@ -50,6 +74,52 @@ ncclDataType_t to_nccl_dtype(int dtype) {
     }
 }
 
+size_t dtype_bytes(int dtype) { return dtype == 0 ? 4 : 2; }
+
+// fp32 -> bf16 with a scale (1 / world size); 8 elements per thread, n is a multiple of 8
+__global__ void pack_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n8, float scale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        __hip_bfloat162 p0 = __float22bfloat162_rn(float2{a.x * scale, a.y * scale});
+        __hip_bfloat162 p1 = __float22bfloat162_rn(float2{a.z * scale, a.w * scale});
+        __hip_bfloat162 p2 = __float22bfloat162_rn(float2{b.x * scale, b.y * scale});
+        __hip_bfloat162 p3 = __float22bfloat162_rn(float2{b.z * scale, b.w * scale});
+        uint4 o;
+        o.x = *reinterpret_cast<uint32_t*>(&p0);
+        o.y = *reinterpret_cast<uint32_t*>(&p1);
+        o.z = *reinterpret_cast<uint32_t*>(&p2);
+        o.w = *reinterpret_cast<uint32_t*>(&p3);
+        dst[i] = o;
+    }
+}
+
+__global__ void unpack_bf16_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, int64_t n8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        // a bf16 is the upper half of the fp32 with the same value
+        float4 a, b;
+        a.x = __uint_as_float(v.x << 16);
+        a.y = __uint_as_float(v.x & 0xffff0000u);
+        a.z = __uint_as_float(v.y << 16);
+        a.w = __uint_as_float(v.y & 0xffff0000u);
+        b.x = __uint_as_float(v.z << 16);
+        b.y = __uint_as_float(v.z & 0xffff0000u);
+        b.z = __uint_as_float(v.w << 16);
+        b.w = __uint_as_float(v.w & 0xffff0000u);
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
+    }
+}
+
+// One increment per executed bucket collective.  Part of the stream work, so a replayed hipGraph
+// counts too: the counter is the evidence that a recorded step really contains its collectives.
+__global__ void count_kernel(unsigned long long* ctr) { atomicAdd(ctr, 1ull); }
+
+int pack_grid(int64_t n8) {
+    const int64_t blocks = (n8 + 255) / 256;
+    return static_cast<int>(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
 }  // namespace
 
 struct PdtComm {
@@ -58,42 +128,95 @@ struct PdtComm {
     int world = 1;
     int device = 0;
     hipStream_t stream = nullptr;  // dedicated communication stream
+    hipEvent_t fence_in = nullptr, fence_out = nullptr;  // ordering of one-off collectives against a caller's stream
+    std::atomic<int> aborted{0};
+};
+
+enum : int {
+    PDT_RCCL_AVERAGE = 1,          // mean instead of sum
+    PDT_RCCL_SCATTER_GATHER = 2,   // reduce-scatter + all-gather instead of all-reduce
+    PDT_RCCL_KEEP_ONE_RANK = 4,    // issue the collective even when the group has one rank
+    PDT_RCCL_COUNT_ON_DEVICE = 8,  // device-side counter of executed bucket collectives
 };
 
 struct PdtRcclBuckets {
     PdtComm* comm = nullptr;
     std::vector<void*> ptr;
+    std::vector<void*> wire;  // bf16 staging buffer of an fp32 bucket, or nullptr: the bucket itself goes on the wire
     std::vector<int64_t> count;
     std::vector<int> dtype;
     std::vector<hipEvent_t> ready;
     std::vector<hipEvent_t> done;
-    hipStream_t compute = nullptr;
-    ncclRedOp_t op = ncclAvg;
-    int errors = 0;
+    int flags = PDT_RCCL_AVERAGE;
+    unsigned long long* device_count = nullptr;
+    std::atomic<int> errors{0};
+    std::atomic<int64_t> bytes_on_wire{0};
 };
 
-static void rccl_launch(void* user, int b) {
+static bool bucket_collective(PdtRcclBuckets* s, int b) {
+    PdtComm* c = s->comm;
+    const bool average = (s->flags & PDT_RCCL_AVERAGE) != 0;
+    const bool on_wire = s->wire[b] != nullptr;
+    const int64_t n = s->count[b];
+    void* buf = on_wire ? s->wire[b] : s->ptr[b];
+    const int dt = on_wire ? 1 : s->dtype[b];
+    if (on_wire) {
+        pack_bf16_kernel<<<pack_grid(n / 8), 256, 0, c->stream>>>(static_cast<const float4*>(s->ptr[b]),
+                                                                 static_cast<uint4*>(buf), n / 8,
+                                                                 average ? 1.0f / static_cast<float>(c->world) : 1.0f);
+        if (!hip_ok(hipGetLastError(), "pack_bf16_kernel")) return false;
+    }
+    // the pack kernel has already divided by the world size
+    const ncclRedOp_t op = (average && !on_wire) ? ncclAvg : ncclSum;
+    if (c->world > 1 || (s->flags & PDT_RCCL_KEEP_ONE_RANK)) {
+        if (s->flags & PDT_RCCL_SCATTER_GATHER) {
+            const size_t shard = static_cast<size_t>(n / c->world);
+            char* mine = static_cast<char*>(buf) + static_cast<size_t>(c->rank) * shard * dtype_bytes(dt);
+            if (!nccl_ok(ncclReduceScatter(buf, mine, shard, to_nccl_dtype(dt), op, c->comm, c->stream), "ncclReduceScatter") ||
+                !nccl_ok(ncclAllGather(mine, buf, shard, to_nccl_dtype(dt), c->comm, c->stream), "ncclAllGather"))
+                return false;
+        } else if (!nccl_ok(ncclAllReduce(buf, buf, static_cast<size_t>(n), to_nccl_dtype(dt), op, c->comm, c->stream),
+                            "ncclAllReduce")) {
+            return false;
+        }
+        s->bytes_on_wire += n * static_cast<int64_t>(dtype_bytes(dt));
+    }
+    if (on_wire) {
+        unpack_bf16_kernel<<<pack_grid(n / 8), 256, 0, c->stream>>>(static_cast<const uint4*>(buf),
+                                                                   static_cast<float4*>(s->ptr[b]), n / 8);
+        if (!hip_ok(hipGetLastError(), "unpack_bf16_kernel")) return false;
+    }
+    if (s->device_count) {
+        count_kernel<<<1, 1, 0, c->stream>>>(s->device_count);
+        if (!hip_ok(hipGetLastError(), "count_kernel")) return false;
+    }
+    return true;
+}
+
+static void rccl_launch(void* user, int b, void* stream) {
     auto* s = static_cast<PdtRcclBuckets*>(user);
-    // A one-rank group has nothing to reduce (sum and mean over one rank are the identity); RCCL would still run
-    // a copy kernel over the whole bucket.  The event chain is kept so the step is ordered as with N ranks.
-    bool ok = hip_ok(hipEventRecord(s->ready[b], s->compute), "hipEventRecord(ready)") &&
+    auto step = static_cast<hipStream_t>(stream);
+    // A one-rank group has nothing to reduce; the event chain is kept so the step is ordered as with N ranks.
+    bool ok = hip_ok(hipEventRecord(s->ready[b], step), "hipEventRecord(ready)") &&
               hip_ok(hipStreamWaitEvent(s->comm->stream, s->ready[b], 0), "hipStreamWaitEvent(comm)") &&
-              (s->comm->world == 1 ||
-               nccl_ok(ncclAllReduce(s->ptr[b], s->ptr[b], static_cast<size_t>(s->count[b]),
-                                     to_nccl_dtype(s->dtype[b]), s->op, s->comm->comm, s->comm->stream),
-                       "ncclAllReduce")) &&
-              hip_ok(hipEventRecord(s->done[b], s->comm->stream), "hipEventRecord(done)");
+              bucket_collective(s, b) && hip_ok(hipEventRecord(s->done[b], s->comm->stream), "hipEventRecord(done)");
     if (!ok) s->errors++;
 }
 
-static void rccl_wait(void* user, int b) {
+static void rccl_wait(void* user, int b, void* stream) {
     auto* s = static_cast<PdtRcclBuckets*>(user);
-    if (!hip_ok(hipStreamWaitEvent(s->compute, s->done[b], 0), "hipStreamWaitEvent(compute)")) s->errors++;
+    if (!hip_ok(hipStreamWaitEvent(static_cast<hipStream_t>(stream), s->done[b], 0), "hipStreamWaitEvent(step)")) s->errors++;
 }
 
 extern "C" {
 
-const char* pdt_rccl_last_error() { return g_last_error.c_str(); }
+// The returned pointer stays valid until the calling thread asks again.
+const char* pdt_rccl_last_error() {
+    thread_local std::string snapshot;
+    std::lock_guard<std::mutex> g(g_err_mu);
+    snapshot = g_last_error;
+    return snapshot.c_str();
+}
 
 int pdt_rccl_unique_id_bytes() { return static_cast<int>(sizeof(ncclUniqueId)); }
 
@@ -116,7 +239,9 @@ PdtComm* pdt_rccl_comm_create(const char* id_bytes, int rank, int world, int dev
         return nullptr;
     }
     if (!hip_ok(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? hi : lo),
-                "hipStreamCreateWithPriority")) {
+                "hipStreamCreateWithPriority") ||
+        !hip_ok(hipEventCreateWithFlags(&c->fence_in, hipEventDisableTiming), "hipEventCreate") ||
+        !hip_ok(hipEventCreateWithFlags(&c->fence_out, hipEventDisableTiming), "hipEventCreate")) {
         delete c;
         return nullptr;
     }
@@ -132,13 +257,41 @@ PdtComm* pdt_rccl_comm_create(const char* id_bytes, int rank, int world, int dev
 
 void pdt_rccl_comm_destroy(PdtComm* c) {
     if (!c) return;
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (!c->aborted.load()) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->comm) (void)ncclCommDestroy(c->comm);
+    }
+    if (c->fence_in) (void)hipEventDestroy(c->fence_in);
+    if (c->fence_out) (void)hipEventDestroy(c->fence_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 void* pdt_rccl_comm_stream(PdtComm* c) { return c->stream; }
+
+// Number of ranks RCCL itself reports for the communicator (-1 on error).
+int pdt_rccl_comm_count(PdtComm* c) {
+    int n = -1;
+    return nccl_ok(ncclCommCount(c->comm, &n), "ncclCommCount") ? n : -1;
+}
+
+// Asynchronous error state of the communicator: 0 = healthy, > 0 = the ncclResult_t RCCL reports (a peer died, a
+// link failed, ...), -1 = the query itself failed.  Cheap enough to poll from a monitoring thread.
+int pdt_rccl_comm_async_error(PdtComm* c) {
+    if (c->aborted.load()) return static_cast<int>(ncclInternalError);
+    ncclResult_t state = ncclSuccess;
+    if (!nccl_ok(ncclCommGetAsyncError(c->comm, &state), "ncclCommGetAsyncError")) return -1;
+    if (state == ncclSuccess || state == ncclInProgress) return 0;
+    set_error(std::string("asynchronous RCCL error: ") + ncclGetErrorString(state));
+    return static_cast<int>(state);
+}
+
+// Tear the communicator down without waiting for outstanding collectives (they can never finish once a peer is
+// gone).  Kernels blocked inside a collective return, so the process can exit instead of hanging.
+int pdt_rccl_comm_abort(PdtComm* c) {
+    if (c->aborted.exchange(1)) return 0;
+    return nccl_ok(ncclCommAbort(c->comm), "ncclCommAbort") ? 0 : -1;
+}
 
 // Collectives on an explicit stream (nullptr = the communicator's own stream).
 int pdt_rccl_allreduce(PdtComm* c, void* buf, int64_t count, int dtype, int average, void* stream) {
@@ -155,6 +308,29 @@ int pdt_rccl_broadcast(PdtComm* c, void* buf, int64_t bytes, int root, void* str
     return nccl_ok(ncclBroadcast(buf, buf, static_cast<size_t>(bytes), ncclInt8, root, c->comm, s), "ncclBroadcast")
                ? 0
                : -1;
+}
+
+// Collectives on the communication stream, ordered after everything already submitted to `step_stream` and before
+// everything submitted to it afterwards (two event edges, no host synchronisation; recordable into a hipGraph).
+// kind: 0 broadcast of `count` bytes from `root`, 1 all-reduce sum, 2 all-reduce mean, 3 all-reduce max.
+int pdt_rccl_ordered(PdtComm* c, int kind, void* buf, int64_t count, int dtype, int root, void* step_stream) {
+    auto step = static_cast<hipStream_t>(step_stream);
+    if (!hip_ok(hipEventRecord(c->fence_in, step), "hipEventRecord(fence_in)") ||
+        !hip_ok(hipStreamWaitEvent(c->stream, c->fence_in, 0), "hipStreamWaitEvent(comm)"))
+        return -1;
+    bool ok;
+    if (kind == 0) {
+        ok = nccl_ok(ncclBroadcast(buf, buf, static_cast<size_t>(count), ncclInt8, root, c->comm, c->stream), "ncclBroadcast");
+    } else {
+        const ncclRedOp_t op = kind == 1 ? ncclSum : (kind == 2 ? ncclAvg : ncclMax);
+        ok = nccl_ok(ncclAllReduce(buf, buf, static_cast<size_t>(count), to_nccl_dtype(dtype), op, c->comm, c->stream),
+                     "ncclAllReduce");
+    }
+    if (!ok) return -1;
+    if (!hip_ok(hipEventRecord(c->fence_out, c->stream), "hipEventRecord(fence_out)") ||
+        !hip_ok(hipStreamWaitEvent(step, c->fence_out, 0), "hipStreamWaitEvent(step)"))
+        return -1;
+    return 0;
 }
 
 int pdt_rccl_stream_sync(PdtComm* c) { return hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize") ? 0 : -1; }
@@ -178,17 +354,36 @@ double pdt_rccl_time_allreduce(PdtComm* c, void* buf, int64_t count, int dtype, 
     return iters > 0 ? 1e3 * ms / iters : 0.0;
 }
 
-PdtRcclBuckets* pdt_rccl_buckets_create(PdtComm* c, int n, void** ptr, const int64_t* count, const int32_t* dtype,
-                                        int average, void* compute_stream) {
+// `wire[i]`: bf16 staging buffer of `count[i]` elements for an fp32 bucket that should cross the links as bf16, or
+// nullptr.  `flags`: PDT_RCCL_* bits.  With PDT_RCCL_SCATTER_GATHER every count must be a multiple of the world
+// size; with a wire buffer, a multiple of 8.
+PdtRcclBuckets* pdt_rccl_buckets_create(PdtComm* c, int n, void** ptr, void** wire, const int64_t* count,
+                                        const int32_t* dtype, int flags) {
     auto* s = new PdtRcclBuckets();
     s->comm = c;
     s->ptr.assign(ptr, ptr + n);
+    if (wire) s->wire.assign(wire, wire + n); else s->wire.assign(n, nullptr);
     s->count.assign(count, count + n);
     s->dtype.assign(dtype, dtype + n);
-    s->op = average ? ncclAvg : ncclSum;
-    s->compute = static_cast<hipStream_t>(compute_stream);
-    s->ready.resize(n);
-    s->done.resize(n);
+    s->flags = flags;
+    for (int i = 0; i < n; ++i) {
+        const bool bad_wire = s->wire[i] && (s->dtype[i] != 0 || s->count[i] % 8 != 0);
+        const bool bad_shard = (flags & PDT_RCCL_SCATTER_GATHER) && s->count[i] % c->world != 0;
+        if (bad_wire || bad_shard) {
+            set_error(bad_wire ? "a bf16 wire buffer needs an fp32 bucket whose length is a multiple of 8"
+                               : "reduce-scatter needs bucket lengths that are multiples of the world size");
+            delete s;
+            return nullptr;
+        }
+    }
+    if ((flags & PDT_RCCL_COUNT_ON_DEVICE) &&
+        (!hip_ok(hipMalloc(&s->device_count, sizeof(unsigned long long)), "hipMalloc") ||
+         !hip_ok(hipMemset(s->device_count, 0, sizeof(unsigned long long)), "hipMemset"))) {
+        delete s;
+        return nullptr;
+    }
+    s->ready.assign(n, nullptr);
+    s->done.assign(n, nullptr);
     for (int i = 0; i < n; ++i) {
         if (!hip_ok(hipEventCreateWithFlags(&s->ready[i], hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming), "hipEventCreate")) {
@@ -201,13 +396,29 @@ PdtRcclBuckets* pdt_rccl_buckets_create(PdtComm* c, int n, void** ptr, const int
 
 void pdt_rccl_buckets_destroy(PdtRcclBuckets* s) {
     if (!s) return;
-    for (auto e : s->ready) (void)hipEventDestroy(e);
-    for (auto e : s->done) (void)hipEventDestroy(e);
+    for (auto e : s->ready)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : s->done)
+        if (e) (void)hipEventDestroy(e);
+    if (s->device_count) (void)hipFree(s->device_count);
     delete s;
 }
 
-void pdt_rccl_buckets_set_compute_stream(PdtRcclBuckets* s, void* stream) { s->compute = static_cast<hipStream_t>(stream); }
-int pdt_rccl_buckets_errors(const PdtRcclBuckets* s) { return s->errors; }
+int pdt_rccl_buckets_errors(const PdtRcclBuckets* s) { return s->errors.load(); }
+
+// Bytes handed to RCCL by bucket collectives so far (host-side count: a replayed hipGraph does not add to it).
+int64_t pdt_rccl_buckets_wire_bytes(const PdtRcclBuckets* s) { return s->bytes_on_wire.load(); }
+
+// Bucket collectives executed on the device so far (needs PDT_RCCL_COUNT_ON_DEVICE; waits for the communication
+// stream).  -1 when the counter is off or the copy failed.
+int64_t pdt_rccl_buckets_device_count(PdtRcclBuckets* s) {
+    if (!s->device_count) return -1;
+    unsigned long long v = 0;
+    if (!hip_ok(hipStreamSynchronize(s->comm->stream), "hipStreamSynchronize") ||
+        !hip_ok(hipMemcpy(&v, s->device_count, sizeof(v), hipMemcpyDeviceToHost), "hipMemcpy"))
+        return -1;
+    return static_cast<int64_t>(v);
+}
 
 pdt_bucket_fn pdt_rccl_launch_fn() { return &rccl_launch; }
 pdt_bucket_fn pdt_rccl_wait_fn() { return &rccl_wait; }

@@ -50,7 +50,12 @@ from .train import TrainConfig, run_training
 @click.option("--bucket-mb", type=float, default=25.0, show_default=True, help="gradient bucket capacity")
 @click.option("--first-bucket-mb", type=float, default=1.0, show_default=True)
 @click.option("--sync-buffers/--no-sync-buffers", default=True, help="broadcast BatchNorm buffers from rank 0 every step")
-@click.option("--native-rccl/--no-native-rccl", default=True, help="bucket all-reduce through the in-repo RCCL transport")
+@click.option("--last-bucket-mb", type=float, default=1.0, show_default=True,
+              help="capacity of the final bucket (the collective nothing overlaps); 0: no separate final bucket")
+@click.option("--grad-dtype", type=click.Choice(["fp32", "bf16"]), default="fp32", show_default=True,
+              help="element type of gradients on the wire (accumulation inside a rank stays fp32)")
+@click.option("--reduce-algorithm", type=click.Choice(["allreduce", "rs_ag"]), default="allreduce", show_default=True,
+              help="per-bucket collective: all-reduce, or reduce-scatter + all-gather (GPU ranks)")
 @click.option("--device-data", is_flag=True, default=False, help="keep synthetic batches resident on the device")
 @click.option("--dataset-length", type=int, default=0)
 @click.option("--seed", type=int, default=0, show_default=True)

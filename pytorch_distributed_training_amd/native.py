@@ -21,7 +21,7 @@ LIB_DIR = Path(__file__).resolve().parent / "_lib"
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
-BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 
 _core: Optional[ctypes.CDLL] = None
 _rccl: Optional[ctypes.CDLL] = None
@@ -34,8 +34,6 @@ class NativeLibraryError(RuntimeError):
 
 def _load(name: str) -> ctypes.CDLL:
     path = LIB_DIR / name
-    if not path.exists() and os.environ.get("PDT_AUTO_BUILD", "1") == "1":
-        _try_build()
     if not path.exists():
         raise NativeLibraryError(
             f"{path} is missing; build the native libraries first: `python csrc/build.py` "
@@ -47,21 +45,6 @@ def _load(name: str) -> ctypes.CDLL:
         raise NativeLibraryError(f"cannot load {path}: {e}") from e
 
 
-def _try_build() -> None:
-    build_py = LIB_DIR.parent.parent / "csrc" / "build.py"
-    if not build_py.exists():
-        return
-    import importlib.util
-
-    spec = importlib.util.spec_from_file_location("_pdt_build", build_py)
-    mod = importlib.util.module_from_spec(spec)
-    try:
-        spec.loader.exec_module(mod)
-        mod.build_all()
-    except Exception:  # a box without compilers: the caller reports the missing file
-        pass
-
-
 def core() -> ctypes.CDLL:
     """Reducer core + loopback fabric (no GPU runtime needed)."""
     global _core
@@ -69,7 +52,7 @@ def core() -> ctypes.CDLL:
         lib = _load("libpdt_core.so")
         lib.pdt_plan_buckets.restype = ctypes.c_int
         lib.pdt_plan_buckets.argtypes = [
-            c_i64p, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            c_i64p, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
             c_i32p, c_i64p, c_i64p,
         ]
         lib.pdt_reducer_create.restype = ctypes.c_void_p
@@ -80,9 +63,9 @@ def core() -> ctypes.CDLL:
         lib.pdt_reducer_destroy.restype = None
         lib.pdt_reducer_prepare.argtypes = [ctypes.c_void_p]
         lib.pdt_reducer_prepare.restype = None
-        lib.pdt_reducer_mark_ready.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.pdt_reducer_mark_ready.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         lib.pdt_reducer_mark_ready.restype = ctypes.c_int
-        lib.pdt_reducer_finalize.argtypes = [ctypes.c_void_p]
+        lib.pdt_reducer_finalize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.pdt_reducer_finalize.restype = ctypes.c_int
         lib.pdt_reducer_ready_order.argtypes = [ctypes.c_void_p, c_i32p]
         lib.pdt_reducer_ready_order.restype = None
@@ -138,16 +121,29 @@ def rccl() -> ctypes.CDLL:
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ]
         lib.pdt_rccl_time_allreduce.restype = ctypes.c_double
+        lib.pdt_rccl_comm_count.argtypes = [ctypes.c_void_p]
+        lib.pdt_rccl_comm_count.restype = ctypes.c_int
+        lib.pdt_rccl_comm_async_error.argtypes = [ctypes.c_void_p]
+        lib.pdt_rccl_comm_async_error.restype = ctypes.c_int
+        lib.pdt_rccl_comm_abort.argtypes = [ctypes.c_void_p]
+        lib.pdt_rccl_comm_abort.restype = ctypes.c_int
+        lib.pdt_rccl_ordered.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+        ]
+        lib.pdt_rccl_ordered.restype = ctypes.c_int
         lib.pdt_rccl_buckets_create.argtypes = [
-            ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p, c_i32p, ctypes.c_int, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i64p, c_i32p,
+            ctypes.c_int,
         ]
         lib.pdt_rccl_buckets_create.restype = ctypes.c_void_p
         lib.pdt_rccl_buckets_destroy.argtypes = [ctypes.c_void_p]
         lib.pdt_rccl_buckets_destroy.restype = None
-        lib.pdt_rccl_buckets_set_compute_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        lib.pdt_rccl_buckets_set_compute_stream.restype = None
         lib.pdt_rccl_buckets_errors.argtypes = [ctypes.c_void_p]
         lib.pdt_rccl_buckets_errors.restype = ctypes.c_int
+        lib.pdt_rccl_buckets_wire_bytes.argtypes = [ctypes.c_void_p]
+        lib.pdt_rccl_buckets_wire_bytes.restype = ctypes.c_int64
+        lib.pdt_rccl_buckets_device_count.argtypes = [ctypes.c_void_p]
+        lib.pdt_rccl_buckets_device_count.restype = ctypes.c_int64
         lib.pdt_rccl_launch_fn.restype = ctypes.c_void_p
         lib.pdt_rccl_wait_fn.restype = ctypes.c_void_p
         _rccl = lib

@@ -3,46 +3,50 @@
 from __future__ import annotations
 
 import torch
-import torch.distributed as dist
 
-from ..utils.logging import get_logger
 from .env import DistEnv, barrier, init_distributed, select_backend, shutdown  # noqa: F401
 from .reducer import BucketedDataParallel, BucketPlan, GradReducer, plan_buckets  # noqa: F401
 from .transport import (  # noqa: F401
     LoopbackFabric,
     LoopbackTransport,
     RcclComm,
+    RcclError,
     RcclTransport,
     TorchDistTransport,
     Transport,
 )
 
 
-def make_transport(env: DistEnv, native_rccl: bool = True) -> Transport:
-    """Pick the bucket transport for this process: own RCCL communicator on GPUs, gloo otherwise."""
+WIRE_DTYPES = {"fp32": None, "bf16": torch.bfloat16}
+
+
+def make_transport(env: DistEnv, grad_dtype: str = "fp32", algorithm: str = "allreduce") -> Transport:
+    """The bucket transport of this process: this package's own RCCL communicator on GPUs, gloo on the CPU.
+
+    There is no second choice on a GPU: when the native library or the communicator cannot be brought up the job
+    stops with the reason.  (Falling back per rank would also deadlock the peers waiting in ``ncclCommInitRank``.)
+    ``grad_dtype``: element type of gradients on the wire (``fp32`` | ``bf16``); ``algorithm``: ``allreduce`` or
+    ``rs_ag`` (reduce-scatter + all-gather, RCCL only)."""
     if not env.distributed:
         raise ValueError("no process group: data parallelism needs --distributed")
-    if env.backend == "nccl" and native_rccl:
-        try:
-            comm = RcclComm(env.rank, env.world_size, env.device)
-        except Exception as e:  # e.g. the native library is missing on this box: say so, keep the job alive
-            ok = torch.tensor([0.0], device=env.device)
-            get_logger("pdt.parallel").warning("own RCCL communicator unavailable (%s); using torch.distributed all-reduce", e)
-        else:
-            ok = torch.tensor([1.0], device=env.device)
-        # every rank must pick the same transport
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok) > 0:
-            return RcclTransport(comm)
-    return TorchDistTransport()
+    if grad_dtype not in WIRE_DTYPES:
+        raise ValueError(f"grad_dtype must be one of {sorted(WIRE_DTYPES)}")
+    wire = WIRE_DTYPES[grad_dtype]
+    if env.backend == "nccl":
+        return RcclTransport(RcclComm(env.rank, env.world_size, env.device), wire_dtype=wire, algorithm=algorithm)
+    if algorithm != "allreduce":
+        raise ValueError("the reduce-scatter + all-gather form needs the RCCL transport (GPU ranks)")
+    return TorchDistTransport(wire_dtype=wire)
 
 
 def wrap_data_parallel(module, env: DistEnv, bucket_mb: float = 25.0, first_bucket_mb: float = 1.0,
-                       broadcast_buffers: bool = True, native_rccl: bool = True) -> BucketedDataParallel:
+                       broadcast_buffers: bool = True, grad_dtype: str = "fp32", algorithm: str = "allreduce",
+                       last_bucket_mb: float = 1.0) -> BucketedDataParallel:
     return BucketedDataParallel(
         module,
-        make_transport(env, native_rccl),
+        make_transport(env, grad_dtype, algorithm),
         bucket_mb=bucket_mb,
         first_bucket_mb=first_bucket_mb,
         broadcast_buffers=broadcast_buffers,
+        last_bucket_mb=last_bucket_mb,
     )

@@ -97,6 +97,10 @@ def init_distributed(distributed: bool, use_cpu: bool = False, timeout_s: float 
     else:
         device = torch.device("cpu")
 
+    if backend == "nccl" and os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+        # a one-node job that meets on the loopback address: let RCCL bootstrap over the loopback interface too,
+        # whatever other interfaces the box has (a container hostname that does not resolve, a NIC without a route)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     owns = False
     if not dist.is_initialized():
         kwargs = dict(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))

@@ -32,7 +32,7 @@ import torch.nn as nn
 
 from .. import native
 from ..utils.logging import get_logger
-from .transport import Transport
+from .transport import Transport, current_stream_handle
 
 log = get_logger("pdt.reducer")
 
@@ -58,12 +58,15 @@ def plan_buckets(
     bucket_bytes: int = 25 * MiB,
     order: Optional[Sequence[int]] = None,
     align_bytes: int = SLOT_ALIGN_BYTES,
+    last_bucket_bytes: int = 0,
 ) -> BucketPlan:
     """Assign parameters to buckets (C++ planner).
 
     Parameters are visited in ``order`` (default: reverse registration order, the order
     in which backward usually produces gradients); bucket 0 is small so the first
-    collective starts early.
+    collective starts early.  ``last_bucket_bytes > 0`` splits the parameters that become
+    ready last into a final bucket of at most that size: its collective is the one nothing
+    overlaps, so it is kept short.
     """
     n = len(numels)
     if n == 0:
@@ -76,7 +79,8 @@ def plan_buckets(
     offsets = (ctypes.c_int64 * n)()
     bbytes = (ctypes.c_int64 * n)()
     nb = lib.pdt_plan_buckets(
-        c_numel, c_esize, n, c_order, int(first_bucket_bytes), int(bucket_bytes), int(align_bytes), bucket_of, offsets, bbytes
+        c_numel, c_esize, n, c_order, int(first_bucket_bytes), int(bucket_bytes), int(last_bucket_bytes), int(align_bytes),
+        bucket_of, offsets, bbytes
     )
     return BucketPlan(list(bucket_of), list(offsets), list(bbytes)[:nb])
 
@@ -91,6 +95,7 @@ class GradReducer:
         bucket_mb: float = 25.0,
         first_bucket_mb: float = 1.0,
         rebuild_after_first_iteration: bool = True,
+        last_bucket_mb: float = 0.0,
     ):
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
@@ -99,6 +104,8 @@ class GradReducer:
         self.world_size = transport.world_size
         self.bucket_bytes = int(bucket_mb * MiB)
         self.first_bucket_bytes = int(first_bucket_mb * MiB)
+        self.last_bucket_bytes = int(last_bucket_mb * MiB)
+        self._on_gpu = self.params[0].is_cuda
         self._lib = native.core()
         self._h = None
         self._sync_enabled = True
@@ -122,7 +129,8 @@ class GradReducer:
     def _build(self, order: Optional[Sequence[int]]) -> None:
         ps = self.params
         self.plan = plan_buckets(
-            [p.numel() for p in ps], [p.element_size() for p in ps], self.first_bucket_bytes, self.bucket_bytes, order
+            [p.numel() for p in ps], [p.element_size() for p in ps], self.first_bucket_bytes, self.bucket_bytes, order,
+            last_bucket_bytes=self.last_bucket_bytes,
         )
         old_views = self.views
         # all buckets of one dtype and device are slices of a single allocation: zero_grad is one memset per group
@@ -134,6 +142,8 @@ class GradReducer:
             p0 = owner[b]
             key = (p0.dtype, p0.device)
             n = nbytes // p0.element_size()
+            mult = max(1, int(getattr(self.transport, "bucket_multiple", 1)))
+            n = (n + mult - 1) // mult * mult  # e.g. whole shards for a reduce-scatter; the padding stays zero
             align = max(1, SLOT_ALIGN_BYTES // p0.element_size())
             start = (group_elems.get(key, 0) + align - 1) // align * align
             place.append((key, start, n))
@@ -180,14 +190,19 @@ class GradReducer:
             self._armed = True
             self._lib.pdt_reducer_prepare(self._h)
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
-        if self._lib.pdt_reducer_mark_ready(self._h, index) < 0:
+        # the stream the gradient kernels of this backward run on: the thread's current stream right now (a hipGraph
+        # capture stream, a user's side stream or the default one) - never a handle remembered from earlier
+        if self._lib.pdt_reducer_mark_ready(self._h, index, self._stream()) < 0:
             raise RuntimeError(
                 f"parameter #{index} reported a complete gradient twice in one backward pass: it receives "
                 "gradient through more than one accumulation node"
             )
 
+    def _stream(self):
+        return current_stream_handle(self.params[0].device) if self._on_gpu else None
+
     def _finalize(self) -> None:
-        self.unused_last = self._lib.pdt_reducer_finalize(self._h)
+        self.unused_last = self._lib.pdt_reducer_finalize(self._h, self._stream())
         self.transport.post_finalize()
         self._armed = False
         self.iterations += 1
@@ -214,6 +229,25 @@ class GradReducer:
             self._build(order=order_list)
 
     # ------------------------------------------------------------------ user API
+    def rebucket(self, bucket_mb: float, first_bucket_mb: Optional[float] = None, last_bucket_mb: Optional[float] = None) -> None:
+        """Re-plan the buckets with new capacities, keeping the observed gradient order and the gradient values.
+        Every rank must call it at the same point (bucket sweeps, tuning)."""
+        self.bucket_bytes = int(bucket_mb * MiB)
+        if first_bucket_mb is not None:
+            self.first_bucket_bytes = int(first_bucket_mb * MiB)
+        if last_bucket_mb is not None:
+            self.last_bucket_bytes = int(last_bucket_mb * MiB)
+        n = len(self.params)
+        buf = (ctypes.c_int32 * n)()
+        self._lib.pdt_reducer_ready_order(self._h, buf)
+        order = list(buf)
+        if self.world_size > 1:  # one order for everybody: rank 0's
+            t = torch.tensor(order, dtype=torch.float32, device=self.buckets[0].device)
+            self.transport.broadcast_(t, src=0)
+            order = [int(v) for v in t.to("cpu").tolist()]
+        self._needs_rebuild = False
+        self._build(order=order if sorted(order) == list(range(n)) else None)
+
     def zero_grad(self) -> None:
         """Zero every gradient with one memset per dtype (``.grad`` stays a bucket view)."""
         for flat in self._flats.values():
@@ -234,16 +268,26 @@ class GradReducer:
     def reduce_now(self) -> None:
         """All-reduce every bucket immediately (outside of backward)."""
         self._lib.pdt_reducer_prepare(self._h)
-        self.unused_last = self._lib.pdt_reducer_finalize(self._h)
+        self.unused_last = self._lib.pdt_reducer_finalize(self._h, self._stream())
         self.transport.post_finalize()
 
     @property
     def launch_count(self) -> int:
         return int(self._lib.pdt_reducer_launch_count(self._h))
 
+    @property
+    def wire_bytes_per_step(self) -> int:
+        """Bytes handed to the collective backend per synchronising backward pass."""
+        return sum(self.transport.wire_bytes(b) for b in self.buckets)
+
     def bucket_summary(self) -> str:
         sizes = ", ".join(f"{b.numel() * b.element_size() / MiB:.1f}" for b in self.buckets)
-        return f"{len(self.buckets)} bucket(s) [MiB: {sizes}] over {len(self.params)} parameter tensors"
+        dtypes = "/".join(sorted({str(b.dtype).replace("torch.", "") for b in self.buckets}))
+        wire = getattr(self.transport, "wire_dtype", None)
+        wire_s = str(wire).replace("torch.", "") if wire is not None else dtypes
+        algo = getattr(self.transport, "algorithm", "allreduce")
+        return (f"{len(self.buckets)} bucket(s) [MiB: {sizes}] over {len(self.params)} parameter tensors; "
+                f"gradients {dtypes}, on the wire {wire_s} via {algo}: {self.wire_bytes_per_step / MiB:.1f} MiB per step")
 
     def close(self) -> None:
         for h in self._hook_handles:
@@ -294,6 +338,8 @@ class BucketedDataParallel(nn.Module):
     rank-0 checkpoint loads straight into an unwrapped model.
     """
 
+    _verify_round = 0
+
     def __init__(
         self,
         module: nn.Module,
@@ -303,13 +349,18 @@ class BucketedDataParallel(nn.Module):
         broadcast_buffers: bool = True,
         init_sync: bool = True,
         group_for_init: Optional[dist.ProcessGroup] = None,
+        last_bucket_mb: float = 0.0,
     ):
         super().__init__()
         self.module = module
         self.transport = transport
         self.broadcast_buffers = broadcast_buffers
         self._group = group_for_init
-        self._use_dist = dist.is_available() and dist.is_initialized() and not _is_loopback(transport)
+        # Collectives of this wrapper go through the transport's own communicator whenever it has one (RCCL,
+        # loopback); torch.distributed carries them only for the gloo transport, which is built on it.
+        from .transport import TorchDistTransport
+
+        self._use_dist = isinstance(transport, TorchDistTransport)
         self._flat_buffers: List[torch.Tensor] = []
         if broadcast_buffers:
             self._flatten_buffers()
@@ -317,7 +368,8 @@ class BucketedDataParallel(nn.Module):
             self._verify_shapes()
             self._broadcast_state()
         self.reducer = GradReducer(
-            [p for p in module.parameters() if p.requires_grad], transport, bucket_mb, first_bucket_mb
+            [p for p in module.parameters() if p.requires_grad], transport, bucket_mb, first_bucket_mb,
+            last_bucket_mb=last_bucket_mb,
         )
 
     # -- construction-time collectives
@@ -326,6 +378,16 @@ class BucketedDataParallel(nn.Module):
         if self._use_dist:
             digests: List[Optional[str]] = [None] * dist.get_world_size(self._group)
             dist.all_gather_object(digests, digest, group=self._group)
+            if any(d != digests[0] for d in digests):
+                raise RuntimeError(f"parameter names/shapes differ across ranks: {digests}")
+        elif dist.is_available() and dist.is_initialized() and not _is_loopback(self.transport):
+            # host-side check through the rendezvous store: no device collective, no second communicator involved
+            store = dist.distributed_c10d._get_default_store()
+            BucketedDataParallel._verify_round += 1
+            prefix = f"pdt/param_digest/{BucketedDataParallel._verify_round}"
+            rank, world = dist.get_rank(), dist.get_world_size()
+            store.set(f"{prefix}/{rank}", digest)
+            digests = [store.get(f"{prefix}/{r}").decode() for r in range(world)]
             if any(d != digests[0] for d in digests):
                 raise RuntimeError(f"parameter names/shapes differ across ranks: {digests}")
 

@@ -71,8 +71,10 @@ class TrainConfig:
     save_every: int = 0  # steps; 0 => only at the end
     bucket_mb: float = 25.0
     first_bucket_mb: float = 1.0
+    last_bucket_mb: float = 1.0
+    grad_dtype: str = "fp32"  # element type of gradients on the wire: fp32 | bf16
+    reduce_algorithm: str = "allreduce"  # allreduce | rs_ag
     sync_buffers: bool = True
-    native_rccl: bool = True
     device_data: bool = False  # keep synthetic batches resident on the device
     dataset_length: int = 0
     seed: int = 0
@@ -150,7 +152,7 @@ class Trainer:
             model = wrap_data_parallel(
                 model, self.env, cfg.bucket_mb, cfg.first_bucket_mb,
                 cfg.sync_buffers and not cfg.hip_graph,  # the per-step buffer broadcast is not part of a recorded step
-                cfg.native_rccl,
+                cfg.grad_dtype, cfg.reduce_algorithm, cfg.last_bucket_mb,
             )
         self.model = model
         # contract line 2 (main.py:59)

@@ -55,3 +55,31 @@ def test_resnet50_bucket_count_is_small():
     total = sum(p.numel() for p in ps) * 4
     assert total == 25_557_032 * 4
     assert 4 <= plan.n_buckets <= 8
+
+
+def test_small_final_bucket_holds_the_parameters_that_become_ready_last():
+    numels = [1000, 2000, 500_000, 500_000, 500_000, 500_000]  # registration order: the small tensors come first
+    plan = plan_buckets(numels, [4] * 6, first_bucket_bytes=1 * MiB, bucket_bytes=8 * MiB, last_bucket_bytes=1 * MiB)
+    last = plan.n_buckets - 1
+    # the two small, first-registered tensors (ready last in backward) sit alone in the final bucket
+    assert [i for i in range(6) if plan.bucket_of[i] == last] == [0, 1]
+    assert plan.bucket_bytes[last] <= 1 * MiB
+    # without the option they share the bucket of their neighbours
+    plain = plan_buckets(numels, [4] * 6, first_bucket_bytes=1 * MiB, bucket_bytes=8 * MiB)
+    assert plain.bucket_of[0] == plain.bucket_of[2]
+    # bucket ids still never decrease along the visiting order
+    rev = [plan.bucket_of[i] for i in reversed(range(6))]
+    assert rev == sorted(rev)
+
+
+def test_final_bucket_never_swallows_everything_or_a_huge_tensor():
+    plan = plan_buckets([10, 10], [4, 4], first_bucket_bytes=1 << 20, bucket_bytes=1 << 20, last_bucket_bytes=1 << 20)
+    assert plan.n_buckets == 2  # the suffix stops before the first visited parameter
+    plan = plan_buckets([4_000_000, 10], [4, 4], first_bucket_bytes=64 << 20, bucket_bytes=64 << 20, last_bucket_bytes=1 << 20)
+    assert plan.n_buckets == 1  # the last-ready tensor alone exceeds the final capacity: nothing is split off
+
+
+def test_final_bucket_respects_element_size_boundaries():
+    plan = plan_buckets([100, 100, 100], [2, 4, 4], first_bucket_bytes=1 << 20, bucket_bytes=1 << 20, last_bucket_bytes=1 << 20)
+    assert plan.bucket_of[0] != plan.bucket_of[1]
+    assert plan.offset_bytes[0] == 0

@@ -87,7 +87,7 @@ def test_reducer_over_rccl_trains_resnet18_like_the_plain_path(one_rank_group):
         assert abs(a - b) < 5e-2 * max(1.0, abs(b))  # atomics make the two runs differ in the last bits only
 
 
-def test_bench_entry_point_runs_under_torchrun_env(one_rank_group):
+def test_wrapped_state_dict_has_no_prefix_and_loads_into_a_plain_model(one_rank_group):
     """`--distributed`-style wrap with WORLD_SIZE=1: state_dict has no prefix, checkpoint is loadable."""
     from pytorch_distributed_training_amd.models import build_model
     from pytorch_distributed_training_amd.parallel import wrap_data_parallel
@@ -100,3 +100,142 @@ def test_bench_entry_point_runs_under_torchrun_env(one_rank_group):
     assert "conv1.weight" in sd and sd["conv1.weight"].is_contiguous() and not any(k.startswith("module.") for k in sd)
     build_model("resnet18", num_classes=10).load_state_dict(sd)
     w.reducer.close()
+
+
+def _resnet18_dp(env, transport, seed=1):
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+    from pytorch_distributed_training_amd.optim import FusedOptimizer
+    from pytorch_distributed_training_amd.parallel import BucketedDataParallel
+
+    torch.manual_seed(seed)
+    m = build_model("resnet18", num_classes=10).to(env.device).to(memory_format=torch.channels_last)
+    ops.prepare_module(m)
+    model = BucketedDataParallel(m, transport, bucket_mb=4.0, first_bucket_mb=0.5, last_bucket_mb=0.25) if transport else m
+    opt = FusedOptimizer(m.parameters(), mode="sgd", lr=0.05, momentum=0.9)
+    return m, model, opt
+
+
+@pytest.mark.parametrize("wire,algorithm", [(None, "allreduce"), (torch.bfloat16, "allreduce"), (None, "rs_ag")])
+def test_recorded_step_executes_the_bucket_collectives_on_every_replay(one_rank_group, wire, algorithm):
+    """Reducer inside a hipGraph: the collectives (kept at world size 1) are nodes of the recorded step - a device
+    counter advances by one per bucket per replay - and the recorded training matches the eager one."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.parallel import RcclComm, RcclTransport
+    from pytorch_distributed_training_amd.train.graph import GraphedStep
+
+    env = one_rank_group
+    dev = env.device
+    torch.manual_seed(0)
+    x = ops.to_device_layout(torch.randn(8, 3, 64, 64, device=dev))
+    y = torch.randint(0, 10, (8,), device=dev)
+
+    def run(graphed):
+        comm = RcclComm(env.rank, env.world_size, dev)
+        tr = RcclTransport(comm, wire_dtype=wire, algorithm=algorithm, keep_one_rank=True, count_on_device=True)
+        m, model, opt = _resnet18_dp(env, tr)
+
+        def body(a, b):
+            loss = ops.softmax_cross_entropy(model(a), b)
+            loss.backward()
+            opt.step()
+            model.reducer.zero_grad()
+            return loss.detach()
+
+        model.reducer.zero_grad()
+        losses = [float(body(x, y)) for _ in range(3)]
+        nb = len(model.reducer.buckets)
+        if graphed:
+            c0 = tr.device_collectives
+            g = GraphedStep(body, opt, (x, y))
+            c1 = tr.device_collectives
+            assert c1 == c0, "capturing must record, not execute"
+            for k in range(4):
+                losses.append(float(g(x, y)))
+                assert tr.device_collectives == c1 + (k + 1) * nb, "a replay did not run every bucket collective"
+        else:
+            opt.set_capturable(True)
+            losses += [float(body(x, y)) for _ in range(4)]
+            assert tr.device_collectives >= 6 * nb
+        params = [p.detach().clone() for p in m.parameters()]
+        model.reducer.close()
+        comm.close()
+        return losses, params
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert la[-1] < la[0]
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 5e-2 * max(1.0, abs(b)), (la, lb)
+
+
+def test_collectives_follow_the_stream_the_step_runs_on(one_rank_group):
+    """A step on a side stream: the bucket collective must wait for the gradient kernels of *that* stream.  The
+    side stream is held back by a long spin kernel, and the wire is bf16 (the unpack kernel rewrites the gradients
+    rounded to bf16): if the collective were ordered against any other stream it would run before the gradients
+    exist, and the gradients found afterwards would not be bf16-representable."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.parallel import RcclComm, RcclTransport
+
+    env = one_rank_group
+    dev = env.device
+    comm = RcclComm(env.rank, env.world_size, dev)
+    tr = RcclTransport(comm, wire_dtype=torch.bfloat16, keep_one_rank=True, count_on_device=True)
+    m, model, _ = _resnet18_dp(env, tr)
+    x = ops.to_device_layout(torch.randn(8, 3, 64, 64, device=dev))
+    y = torch.randint(0, 10, (8,), device=dev)
+    model.reducer.zero_grad()
+    ops.softmax_cross_entropy(model(x), y).backward()  # first pass: buckets are re-planned after it
+    model.reducer.zero_grad()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(200_000_000)  # ~0.1 s before anything else on this stream runs
+        ops.softmax_cross_entropy(model(x), y).backward()
+    side.synchronize()
+    comm.synchronize()
+    torch.cuda.synchronize()
+    assert tr.device_collectives == len(model.reducer.buckets)  # the counter restarted with the re-planned buckets
+    for name, p in m.named_parameters():
+        g = p.grad
+        assert float(g.abs().max()) > 0, name
+        assert torch.equal(g, g.to(torch.bfloat16).to(torch.float32)), f"{name}: gradient did not pass through the wire"
+    model.reducer.close()
+    comm.close()
+
+
+def test_ordered_collectives_and_failure_probes(one_rank_group):
+    from pytorch_distributed_training_amd.parallel import RcclComm
+
+    env = one_rank_group
+    comm = RcclComm(env.rank, env.world_size, env.device)
+    assert comm.rccl_ranks == 1
+    t = torch.full((16,), 3.0, device=env.device)
+    comm.ordered_all_reduce_(t, "sum")
+    comm.ordered_all_reduce_(t, "max")
+    comm.ordered_broadcast_(t, 0)
+    assert torch.equal(t.cpu(), torch.full((16,), 3.0))  # the copy runs on the current stream, after the fence
+    assert comm.async_error() is None
+    comm.abort()
+    assert comm.async_error() is not None
+    comm.close()
+
+
+def test_bench_py_prints_one_json_line_with_sync_proofs():
+    """bench.py as the driver starts it on one GPU (small batch so it takes seconds)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--batch-size", "32"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["model"] == "resnet50" and rec["value"] > 0
+    ex = rec["extras"]
+    assert ex["transport"] == "RcclTransport" and ex["rccl_ranks"] == 1 and ex["params_in_sync"] is True
+    assert ex["rank_sum"]["got"] == ex["rank_sum"]["expected"] == 1.0 and "error" not in ex
