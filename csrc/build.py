@@ -9,6 +9,9 @@ Produces, under ``pytorch_distributed_training_amd/_lib/``:
 The libraries expose a C ABI and are loaded with ctypes, so the build needs no PyTorch
 headers and a cold build takes well under a minute.  hipcc cross-compiles without a GPU.
 Objects are rebuilt only when a source or header is newer.
+
+``--sanitize address|thread|undefined`` builds, instead, the host-only stress driver of the reducer core and the
+loopback fabric under that sanitizer (``build/san/reducer_stress_<kind>``); ``tests/test_sanitizers.py`` runs all three.
 """
 
 from __future__ import annotations
@@ -60,6 +63,29 @@ def build_core(force: bool = False) -> Path:
     if force or _newer(out, deps):
         cxx = os.environ.get("CXX", "g++")
         _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-o", str(out)] + [str(s) for s in srcs])
+    return out
+
+
+SANITIZERS = ("address", "thread", "undefined")
+
+
+def build_sanitized(kind: str, force: bool = False) -> Path:
+    """Host-only sanitizer build of the reducer core + loopback fabric with their stress driver
+    (``csrc/reducer/reducer_stress.cpp``): an executable under ``build/san/``.  GPU code is not involved, so the
+    sanitizers run anywhere; run the result directly (``build/san/reducer_stress_thread``)."""
+    if kind not in SANITIZERS:
+        raise ValueError(f"--sanitize takes one of {SANITIZERS}")
+    out_dir = ROOT / "build" / "san"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    srcs = [CSRC / "reducer" / "reducer_core.cpp", CSRC / "reducer" / "loopback.cpp", CSRC / "reducer" / "reducer_stress.cpp"]
+    deps = srcs + [CSRC / "reducer" / "reducer_core.h"]
+    out = out_dir / f"reducer_stress_{kind}"
+    if force or _newer(out, deps):
+        cxx = os.environ.get("CXX", "g++")
+        flags = [f"-fsanitize={kind}", "-fno-omit-frame-pointer", "-g", "-O1"]
+        if kind == "undefined":
+            flags.append("-fno-sanitize-recover=all")
+        _run([cxx, "-std=c++17", "-pthread", "-Wall", *flags, "-o", str(out)] + [str(s) for s in srcs])
     return out
 
 
@@ -124,6 +150,11 @@ def build_all(force: bool = False) -> List[Path]:
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--sanitize", choices=SANITIZERS, default=None,
+                    help="build the host-only sanitizer stress driver of the reducer core instead of the libraries")
     args = ap.parse_args()
-    for p in build_all(args.force):
-        print(p)
+    if args.sanitize:
+        print(build_sanitized(args.sanitize, args.force))
+    else:
+        for p in build_all(args.force):
+            print(p)

@@ -34,7 +34,8 @@ from .train import TrainConfig, run_training
 @click.option("--image-size", type=int, default=0, help="0: model default (32 for resnet18, 224 otherwise)")
 @click.option("--seq-len", type=int, default=1024, show_default=True)
 @click.option("--epochs", type=int, default=1, show_default=True)
-@click.option("--steps", type=int, default=0, help="stop after this many optimisation steps (0: full epochs)")
+@click.option("--steps", type=int, default=0,
+              help="stop once this many optimisation steps have been taken in total, resumed steps included (0: full epochs)")
 @click.option("--warmup-steps", type=int, default=0, help="steps excluded from the throughput measurement")
 @click.option("--dtype", type=click.Choice(["auto", "fp32", "bf16"]), default="auto", show_default=True)
 @click.option("--optimizer", type=click.Choice(["adam", "adamw", "sgd"]), default="adam", show_default=True)
@@ -45,7 +46,8 @@ from .train import TrainConfig, run_training
 @click.option("--train-split", is_flag=True, default=False, help="use the CIFAR-10 training split (reference uses the test split)")
 @click.option("--eval", "evaluate", is_flag=True, default=False, help="run the evaluation loop after training")
 @click.option("--checkpoint-path", type=str, default="", help="rank 0 writes model.state_dict() here")
-@click.option("--resume", type=str, default="", help="checkpoint to restore before training")
+@click.option("--resume", type=str, default="",
+              help="checkpoint to restore before training; 'auto': --checkpoint-path when it exists (restartable job lines)")
 @click.option("--save-every", type=int, default=0, help="also checkpoint every N steps")
 @click.option("--bucket-mb", type=float, default=25.0, show_default=True, help="gradient bucket capacity")
 @click.option("--first-bucket-mb", type=float, default=1.0, show_default=True)
@@ -63,6 +65,11 @@ from .train import TrainConfig, run_training
 @click.option("--progress/--no-progress", default=True)
 @click.option("--watchdog-s", type=float, default=0.0, help="abort when no step finishes for this many seconds")
 @click.option("--dist-timeout-s", type=float, default=600.0, show_default=True)
+@click.option("--comm-poll-s", type=float, default=2.0, show_default=True,
+              help="seconds between queries of RCCL's asynchronous error state (0: never); an error aborts the communicator "
+                   "and ends the process so a supervisor can restart the job")
+@click.option("--stop-check-every", type=int, default=0,
+              help="steps between the ranks' agreements on stop requests (0: every step on CPU, every 16 on GPU)")
 @click.option("--profile", type=str, default="", help="write a chrome trace of host-side phases to this path")
 @click.option("--check-finite", is_flag=True, default=False)
 @click.option("--hip-graph", is_flag=True, default=False,

@@ -27,17 +27,17 @@ def build_loader(
     drop_last: bool = False,
     pin_memory: bool = False,
     seed: int = 0,
-) -> Tuple[DataLoader, Optional[ShardedSampler]]:
+) -> Tuple[DataLoader, ShardedSampler]:
     """``batch_size`` is per process, as in the reference (main.py:61)."""
-    sampler = None
-    if world_size > 1:
-        sampler = ShardedSampler(dataset, world_size, rank, shuffle=shuffle, seed=seed, drop_last=drop_last)
+    # one sampler class for any world size (a single process is a one-replica shard): the order depends only on
+    # (seed, epoch), and a pass can start behind the samples a resumed job has already seen
+    sampler = ShardedSampler(dataset, world_size, rank, shuffle=shuffle, seed=seed, drop_last=drop_last)
     loader = DataLoader(
         dataset,
         batch_size=batch_size,
         num_workers=num_workers,
         sampler=sampler,
-        shuffle=(shuffle and sampler is None),
+        shuffle=False,
         drop_last=drop_last,
         pin_memory=pin_memory,
         persistent_workers=num_workers > 0,
@@ -87,12 +87,18 @@ class DeviceSyntheticLoader:
     def __init__(self, make_batch, steps: int, n_resident: int = 2):
         self.batches = [make_batch(i) for i in range(max(1, n_resident))]
         self.steps = steps
+        self._skip = 0
 
     def __len__(self) -> int:
         return self.steps
 
+    def skip_next(self, n: int) -> None:
+        """Start the next pass at batch ``n`` (resuming inside an epoch)."""
+        self._skip = max(0, int(n))
+
     def __iter__(self):
-        for i in range(self.steps):
+        start, self._skip = self._skip, 0
+        for i in range(start, self.steps):
             yield self.batches[i % len(self.batches)]
 
 

@@ -36,6 +36,7 @@ class ShardedSampler(Sampler[int]):
         self.seed = seed
         self.drop_last = drop_last
         self.epoch = 0
+        self._start = 0
         if drop_last and self.n % num_replicas != 0:
             self.num_samples = self.n // num_replicas  # tail dropped: every index used at most once
         else:
@@ -45,6 +46,10 @@ class ShardedSampler(Sampler[int]):
     def set_epoch(self, epoch: int) -> None:
         """Change the permutation; call once per epoch with the same value on every rank."""
         self.epoch = int(epoch)
+
+    def set_start(self, n_samples: int) -> None:
+        """Skip the first ``n_samples`` of this rank's shard in the *next* pass only (resuming inside an epoch)."""
+        self._start = max(0, int(n_samples))
 
     def _global_order(self) -> list:
         if self.shuffle:
@@ -61,7 +66,8 @@ class ShardedSampler(Sampler[int]):
 
     def __iter__(self) -> Iterator[int]:
         order = self._global_order()
-        return iter(order[self.rank : self.total_size : self.num_replicas])
+        start, self._start = self._start, 0
+        return iter(order[self.rank : self.total_size : self.num_replicas][start:])
 
     def __len__(self) -> int:
         return self.num_samples

@@ -106,6 +106,9 @@ def init_distributed(distributed: bool, use_cpu: bool = False, timeout_s: float 
         kwargs = dict(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
             kwargs["device_id"] = device  # eager communicator bound to this rank's GPU
+        store = _restart_scoped_store(world_size, timeout_s)
+        if store is not None:
+            kwargs.update(store=store, rank=rank, world_size=world_size)
         dist.init_process_group(**kwargs)
         owns = True
     set_rank(dist.get_rank())
@@ -117,6 +120,21 @@ def init_distributed(distributed: bool, use_cpu: bool = False, timeout_s: float 
         device=device,
         owns_group=owns,
     )
+
+
+def _restart_scoped_store(world_size: int, timeout_s: float):
+    """Under a launcher that restarts failed worker groups (``torchrun --max-restarts``) with a fixed
+    ``--master-addr/--master-port``, the launcher's key-value store outlives the workers: the addresses the previous
+    incarnation published are still in it, and a restarted rank that reads one before its peer has overwritten it
+    connects to a process that no longer exists.  Scope every key of this incarnation by the restart count.
+    Returns ``None`` when the process was not started by such a launcher (plain ``env://`` initialisation)."""
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") != "True" or "TORCHELASTIC_RESTART_COUNT" not in os.environ:
+        return None
+    if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+        return None
+    base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world_size, is_master=False,
+                         timeout=datetime.timedelta(seconds=timeout_s))
+    return dist.PrefixStore(f"/pdt/attempt_{os.environ['TORCHELASTIC_RESTART_COUNT']}", base)
 
 
 def barrier(env: DistEnv) -> None:

@@ -10,6 +10,8 @@ detection.  The five printed contract lines are preserved verbatim.
 from __future__ import annotations
 
 import math
+import os
+import sys
 import time
 from dataclasses import dataclass, field
 from typing import Any, Dict, Optional
@@ -56,7 +58,7 @@ class TrainConfig:
     image_size: int = 0
     seq_len: int = 1024
     epochs: int = 1
-    steps: int = 0  # >0: stop after this many optimisation steps in total
+    steps: int = 0  # >0: stop once this many optimisation steps have been taken in total (resumed steps count)
     warmup_steps: int = 0  # steps excluded from the throughput window
     dtype: str = "auto"  # auto: bf16 on GPU, fp32 on CPU
     optimizer: str = "adam"
@@ -67,7 +69,7 @@ class TrainConfig:
     train_split: bool = False  # reference trains on the CIFAR-10 *test* split (main.py:47)
     evaluate: bool = False
     checkpoint_path: str = ""
-    resume: str = ""
+    resume: str = ""  # checkpoint to restore; "auto": --checkpoint-path when it exists (restartable job lines)
     save_every: int = 0  # steps; 0 => only at the end
     bucket_mb: float = 25.0
     first_bucket_mb: float = 1.0
@@ -81,6 +83,8 @@ class TrainConfig:
     log_every: int = 0
     progress: bool = True
     watchdog_s: float = 0.0
+    comm_poll_s: float = 2.0  # how often the watchdog thread asks RCCL for asynchronous errors (0: never)
+    stop_check_every: int = 0  # steps between the ranks' agreements on stop requests; 0: every step on CPU, 16 on GPU
     dist_timeout_s: float = 600.0
     profile: str = ""  # path of a chrome trace with per-phase host spans
     check_finite: bool = False
@@ -164,10 +168,21 @@ class Trainer:
         )
         self.start_epoch = 0
         self.global_step = 0
-        if cfg.resume:
-            info = ckpt.load_checkpoint(cfg.resume, self.model, self.optimizer)
+        self.start_batch = 0  # micro-batches of ``start_epoch`` already consumed before the checkpoint was written
+        resume = cfg.resume
+        if resume == "auto":
+            resume = cfg.checkpoint_path if (cfg.checkpoint_path and os.path.exists(cfg.checkpoint_path)) else ""
+        if resume:
+            info = ckpt.load_checkpoint(resume, self.model, self.optimizer)
             self.start_epoch, self.global_step = info["epoch"], info["step"]
-            rank_zero_print(f"Resumed from {cfg.resume} at epoch {self.start_epoch}, step {self.global_step}")
+            self.start_batch = int(info.get("extra", {}).get("batch_in_epoch", 0))
+            # the saved generator state is rank 0's; giving it to every rank would make their random streams equal
+            if info.get("torch_rng") is not None and self.env.rank == 0:
+                torch.set_rng_state(info["torch_rng"])
+            elif self.env.rank != 0:
+                torch.manual_seed(cfg.seed + 1_000_003 * self.env.rank + self.global_step)
+            rank_zero_print(f"Resumed from {resume} at epoch {self.start_epoch}, step {self.global_step}"
+                            + (f", batch {self.start_batch} of the epoch" if self.start_batch else ""))
         self.timer = StepTimer(self.device, enabled=bool(cfg.profile))
         self.trace = ChromeTrace(self.env.rank) if cfg.profile else None
         self.stopper = GracefulStop()
@@ -255,9 +270,12 @@ class Trainer:
             return self._graph(*inputs)
         return self._graph_body(*inputs)
 
-    def train_step(self, batch, accumulate: bool = False) -> torch.Tensor:
-        """forward + backward (+ optimizer step unless ``accumulate``); returns the detached loss."""
+    def train_step(self, batch, accumulate: bool = False, group_size: Optional[int] = None) -> torch.Tensor:
+        """forward + backward (+ optimizer step unless ``accumulate``); returns the detached loss.
+        ``group_size``: number of micro-batches whose gradients are summed into this optimizer step (default
+        ``--grad-accum``; smaller for the incomplete group at the end of an epoch): the loss is divided by it."""
         cfg = self.cfg
+        group_size = group_size or cfg.grad_accum
         if self._use_graph:
             return self._graphed_train_step(batch)
         span = self.trace.span if self.trace else None
@@ -265,8 +283,8 @@ class Trainer:
         with sync_ctx:
             with self.timer.phase("forward"), (span("forward") if span else _null()):
                 loss = self._forward_loss(batch)
-                if cfg.grad_accum > 1:
-                    loss = loss / cfg.grad_accum
+                if group_size > 1:
+                    loss = loss / group_size
             with self.timer.phase("backward"), (span("backward") if span else _null()):
                 loss.backward()
         if not accumulate:
@@ -274,6 +292,34 @@ class Trainer:
                 self.optimizer.step()
                 self._zero_grad()
         return loss.detach()
+
+    # ------------------------------------------------------------------ loops
+    # ------------------------------------------------------------------ agreement between ranks
+    def _agree(self, flags: int) -> int:
+        """Bitwise OR over ranks of a small set of flags, so every rank takes the same decision at the same step.
+
+        A stop request (SIGTERM reaches ranks at different moments, or only one of them) or a non-finite loss acted
+        on by one rank alone leaves the others blocked in the next bucket collective."""
+        env = self.env
+        if not env.distributed:
+            return flags
+        t = torch.tensor([float(flags & 1), float(flags >> 1 & 1)], dtype=torch.float32, device=self.device)
+        comm = getattr(getattr(self.model, "transport", None), "comm", None)
+        if comm is not None:
+            comm.ordered_all_reduce_(t, "max")
+        else:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        a, b = t.tolist()
+        return int(a > 0) | (int(b > 0) << 1)
+
+    def _comm_probe(self):
+        comm = getattr(getattr(self.model, "transport", None), "comm", None)
+        return comm.async_error if (comm is not None and self.cfg.comm_poll_s > 0) else None
+
+    def _abort_comm(self) -> None:
+        comm = getattr(getattr(self.model, "transport", None), "comm", None)
+        if comm is not None:
+            comm.abort()
 
     # ------------------------------------------------------------------ loops
     def fit(self) -> TrainResult:
@@ -286,46 +332,89 @@ class Trainer:
         self.model.train()
         self._zero_grad()
         self.stopper.install()
-        dog = StepWatchdog(cfg.watchdog_s, env.rank).start()
+        dog = StepWatchdog(cfg.watchdog_s, env.rank, probe=self._comm_probe(), probe_every_s=cfg.comm_poll_s,
+                           before_exit=self._abort_comm).start()
+        check_every = cfg.stop_check_every or (1 if self.device.type == "cpu" else 16)
+        ga = max(1, cfg.grad_accum)
 
+        if os.environ.get("PDT_TEST_PIDFILE_RANK1") and env.rank == 1:  # lets a test signal exactly this rank
+            with open(os.environ["PDT_TEST_PIDFILE_RANK1"], "w") as f:
+                f.write(str(os.getpid()))
         t0 = time.perf_counter()
         print("Training starting...", flush=True)  # contract line 3 (main.py:66)
         meter.start()
         done = False
+        stopped = False
         last_loss = None
         steps_this_run = 0
+        pending = 0  # bit 0: stop requested here, bit 1: non-finite loss seen here; not yet agreed with the other ranks
         epoch = self.start_epoch
+        batch_in_epoch = 0
         try:
+            if cfg.steps and self.global_step >= cfg.steps:
+                done = True
             for epoch in range(self.start_epoch, cfg.epochs):
+                if done:
+                    break
                 if sampler is not None:
                     sampler.set_epoch(epoch)
-                bar = tqdm(loader, disable=not (cfg.progress and env.is_main), desc=f"epoch {epoch}" if cfg.epochs > 1 else None)
-                micro = 0
+                # a checkpoint written in the middle of an epoch: continue behind the batches already trained on
+                skip = self.start_batch if epoch == self.start_epoch else 0
+                n_batches = len(loader)
+                if skip:
+                    if skip >= n_batches:
+                        skip = 0
+                    elif sampler is not None:
+                        sampler.set_start(skip * cfg.batch_size)
+                    else:
+                        loader.skip_next(skip)
+                bar = tqdm(loader, disable=not (cfg.progress and env.is_main), desc=f"epoch {epoch}" if cfg.epochs > 1 else None,
+                           total=n_batches - skip)
+                micro = skip
                 for batch in bar:
+                    # micro-batches [group_start, group_start + group_size) feed one optimizer step; the last group of
+                    # an epoch may be short (its loss is scaled by its own size and it still steps: nothing leaks into
+                    # the next epoch, nothing is dropped)
+                    group_start = (micro // ga) * ga
+                    group_size = min(ga, n_batches - group_start)
                     micro += 1
-                    accumulate = (micro % cfg.grad_accum) != 0
-                    last_loss = self.train_step(batch, accumulate)
+                    accumulate = (micro - group_start) < group_size
+                    last_loss = self.train_step(batch, accumulate, group_size)
                     if accumulate:
                         continue
+                    batch_in_epoch = micro
                     self.global_step += 1
                     steps_this_run += 1
-                    meter.step(_batch_len(batch) * cfg.grad_accum)
+                    meter.step(_batch_len(batch) * group_size)
                     dog.beat(self.global_step)
                     maybe_inject_fault(env.rank, self.global_step)
                     if cfg.log_every and self.global_step % cfg.log_every == 0:
-                        lv = float(last_loss) * cfg.grad_accum
+                        lv = float(last_loss) * group_size
                         loss_meter.update(lv)
                         res.losses.append(lv)
                         if cfg.check_finite and not math.isfinite(lv):
-                            raise FloatingPointError(f"non-finite loss {lv} at step {self.global_step}")
+                            pending |= 2
                         if env.is_main:
                             bar.set_postfix(loss=f"{lv:.4f}", refresh=False)
+                    if self.stopper.requested:
+                        pending |= 1
+                    if not env.distributed or self.global_step % check_every == 0:
+                        # every rank evaluates this condition at the same step, so the collective inside _agree is
+                        # entered by all of them; flags raised between two agreement steps wait for the next one
+                        agreed = self._agree(pending)
+                        if agreed & 2:
+                            raise FloatingPointError(f"non-finite loss at or before step {self.global_step} on some rank")
+                        if agreed & 1:
+                            stopped = done = True
                     if cfg.save_every and cfg.checkpoint_path and self.global_step % cfg.save_every == 0:
-                        self.save(epoch)
-                    if self.stopper.requested or (cfg.steps and steps_this_run >= cfg.steps):
+                        self.save(epoch, batch_in_epoch)
+                    if cfg.steps and self.global_step >= cfg.steps:
                         done = True
+                    if done:
                         break
                 res.epochs = epoch + 1 - self.start_epoch
+                if not done:
+                    batch_in_epoch = 0
                 if done:
                     break
         finally:
@@ -340,9 +429,9 @@ class Trainer:
         res.elapsed_s = t1 - t0
         res.samples_per_sec = meter.samples_per_sec
         res.ms_per_step = meter.ms_per_step
-        res.interrupted = self.stopper.requested
+        res.interrupted = stopped
         if last_loss is not None:
-            res.final_loss = float(last_loss) * cfg.grad_accum
+            res.final_loss = float(last_loss) * min(ga, max(1, len(loader)))
         unit = "tokens/sec" if self.kind == "lm" else "images/sec"
         scale = cfg.seq_len if self.kind == "lm" else 1
         if meter.timed_steps:
@@ -357,7 +446,10 @@ class Trainer:
             else:
                 rank_zero_print(f"Eval: loss {res.eval_loss:.4f}")
         if cfg.checkpoint_path:
-            self.save(epoch + (0 if done else 1))
+            if done and batch_in_epoch:
+                self.save(epoch, batch_in_epoch)  # stopped inside an epoch: a resume continues behind this batch
+            else:
+                self.save(epoch + 1, 0)
             rank_zero_print(f"Checkpoint written to {cfg.checkpoint_path}")
         if cfg.profile:
             if self.trace and env.is_main:
@@ -398,8 +490,9 @@ class Trainer:
         acc = float(tot[1]) / count if self.kind == "image" else None
         return float(tot[0]) / count, acc
 
-    def save(self, epoch: int) -> None:
-        ckpt.save_checkpoint(self.cfg.checkpoint_path, self.model, self.env, self.optimizer, epoch, self.global_step)
+    def save(self, epoch: int, batch_in_epoch: int = 0) -> None:
+        ckpt.save_checkpoint(self.cfg.checkpoint_path, self.model, self.env, self.optimizer, epoch, self.global_step,
+                             extra={"batch_in_epoch": int(batch_in_epoch)})
 
     def close(self) -> None:
         if hasattr(self.model, "reducer"):

@@ -27,11 +27,29 @@ WATCHDOG_EXIT_CODE = 75  # EX_TEMPFAIL: "try again" - a restart is expected to s
 
 
 class StepWatchdog:
-    def __init__(self, timeout_s: float, rank: int = 0, on_timeout=None, poll_s: Optional[float] = None):
+    """``timeout_s > 0``: no finished step for that long is a failure.  ``probe``: a callable polled every
+    ``probe_every_s`` that returns ``None`` while the communication backend is healthy and a description once it
+    has reported an asynchronous error (``RcclComm.async_error``: a dead peer is then noticed within seconds
+    instead of after the step timeout).  On either failure: stacks are dumped, ``before_exit`` runs (abort the
+    communicator, so kernels blocked in a collective return), and the process ends with ``WATCHDOG_EXIT_CODE`` -
+    it is never re-executed in place; a supervisor (``torchrun --max-restarts``) starts a fresh one."""
+
+    def __init__(self, timeout_s: float, rank: int = 0, on_timeout=None, poll_s: Optional[float] = None,
+                 probe=None, probe_every_s: float = 2.0, before_exit=None):
         self.timeout_s = float(timeout_s)
         self.rank = rank
         self.on_timeout = on_timeout
-        self.poll_s = poll_s if poll_s is not None else max(min(self.timeout_s / 4.0, 5.0), 0.01)
+        self.probe = probe
+        self.before_exit = before_exit
+        self.failure: Optional[str] = None
+        if poll_s is not None:
+            self.poll_s = poll_s
+        elif self.timeout_s > 0:
+            self.poll_s = max(min(self.timeout_s / 4.0, 5.0), 0.01)
+            if probe is not None:
+                self.poll_s = min(self.poll_s, max(probe_every_s, 0.01))
+        else:
+            self.poll_s = max(probe_every_s, 0.01)
         self._last = time.monotonic()
         self._step = 0
         self._stop = threading.Event()
@@ -39,7 +57,7 @@ class StepWatchdog:
         self.fired = False
 
     def start(self) -> "StepWatchdog":
-        if self.timeout_s > 0 and self._thread is None:
+        if (self.timeout_s > 0 or self.probe is not None) and self._thread is None:
             self._last = time.monotonic()
             self._thread = threading.Thread(target=self._run, name="pdt-watchdog", daemon=True)
             self._thread.start()
@@ -60,19 +78,33 @@ class StepWatchdog:
     def _run(self) -> None:
         while not self._stop.wait(self.poll_s):
             stalled = time.monotonic() - self._last
-            if stalled > self.timeout_s:
+            why = None
+            if self.timeout_s > 0 and stalled > self.timeout_s:
+                why = f"no step finished for {stalled:.1f}s (last step {self._step})"
+            elif self.probe is not None:
+                try:
+                    err = self.probe()
+                except Exception as e:  # the probe itself failing is a failure of the backend
+                    err = repr(e)
+                if err:
+                    why = f"communication backend reports: {err} (last step {self._step})"
+            if why is not None:
                 self.fired = True
-                sys.stderr.write(
-                    f"[pdt watchdog] rank {self.rank}: no step finished for {stalled:.1f}s "
-                    f"(last step {self._step}); dumping stacks\n"
-                )
+                self.failure = why
+                sys.stderr.write(f"[pdt watchdog] rank {self.rank}: {why}; dumping stacks\n")
                 try:
                     faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 except Exception:
                     pass
+                if self.before_exit is not None:
+                    try:
+                        self.before_exit()
+                    except Exception:
+                        pass
                 if self.on_timeout is not None:
                     self.on_timeout()
                 else:
+                    sys.stderr.flush()
                     os._exit(WATCHDOG_EXIT_CODE)
                 return
 

@@ -13,6 +13,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
     config.addinivalue_line("markers", "slow: multi-process or long-running CPU test")
+    config.addinivalue_line("markers", "sanitize: native reducer stress driver under ASan / TSan / UBSan (host code only)")
 
 
 def _has_gpu() -> bool:
