@@ -371,9 +371,19 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // K-step, so the loader keeps running 64-bit pointers (one add per piece and stage instead of a dozen vector
 // ALU instructions of bounds checks and index arithmetic) and issues unconditionally - past its last tile from
 // the zero page - which puts loads and MFMAs of a K-step into one basic block for the scheduler to interleave.
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK, bool PLAIN = false>
+//
+// PP ("ping-pong", 256x256 tile, 2 x 4 waves, two stages): the K-step is cut into four phases of 16 MFMAs (one
+// quadrant of the wave's 128x64 output each), every phase bracketed by two workgroup barriers, and the wave rows run
+// one barrier apart: while the waves of row 0 issue the MFMAs of a phase, the waves of row 1 - one per SIMD next to
+// them - issue their fragment reads and LDS-DMA requests, and vice versa, so the matrix pipe of every SIMD always has
+// a wave feeding it while the other wave's LDS traffic is hidden behind it (with one schedule for all eight waves,
+// both waves of a SIMD read at the same time and then both compete for the matrix pipe).  Operands are staged in
+// units of 128 rows (the rows of one phase: the lower or upper half of every wave's A rows or B columns), one unit
+// per phase, six units ahead of the reads, with a counted wait that leaves four units in flight across the barriers.
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK, bool PLAIN = false, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const GatherGemmArgs p) {
     constexpr int NW = WM * WN;
+    static_assert(!PP || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64), "ping-pong schedule: 256x256, 2x4 waves");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int PR = 512 / BK;                            // rows per 1 KB DMA piece (8 rows of 128 B or 16 of 64 B)
@@ -419,11 +429,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     int ld_tile = first, ld_t = 0, ld_c0 = 0, ld_issued = 0, ld_slot = 0;
     int a_pix[AI], a_h[AI], a_w[AI];
     int b_off[BI];
+    // First tile row of this wave's DMA piece i.  Plain ring: consecutive pieces.  Ping-pong: pieces 2i' and 2i'+1 of
+    // staging unit i >> 1 (A: rows [64u, 64u + 64) of both wave rows; B: columns [32v, 32v + 32) of all four wave columns).
+    auto row_a = [&](int i) {
+        if constexpr (PP) {
+            const int q = 2 * wave + (i & 1);
+            return (q >> 3) * 128 + (i >> 1) * 64 + (q & 7) * 8;
+        } else {
+            return (wave * AI + i) * PR;
+        }
+    };
+    auto row_b = [&](int i) {
+        if constexpr (PP) {
+            const int q = 2 * wave + (i & 1);
+            return (q >> 2) * 64 + (i >> 1) * 32 + (q & 3) * 8;
+        } else {
+            return (wave * BI + i) * PR;
+        }
+    };
     auto loader_tile = [&](int tile) {
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int m = tile_m * BM + (wave * AI + i) * PR + lrow;
+            const int m = tile_m * BM + row_a(i) + lrow;
             if (m < p.M) {
                 const uint32_t img = fastdiv(m, p.div_ab);
                 const uint32_t rem = m - img * (p.OA * p.OB);
@@ -440,28 +468,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int n = tile_n * BN + (wave * BI + i) * PR + lrow;
+            const int n = tile_n * BN + row_b(i) + lrow;
             b_off[i] = n < p.N ? n * p.ldb : -1;
         }
     };
-    auto issue_stage = [&]() {
+    // pieces [a_lo, a_hi) of the A tile and [b_lo, b_hi) of the B tile of the stage under the cursor
+    auto issue_pieces = [&](int a_lo, int a_hi, int b_lo, int b_hi) {
         const int dh = p.tap_dh[ld_t], dw = p.tap_dw[ld_t], woff = p.tap_woff[ld_t] + ld_c0 + kchunk;
         bf16* sA = ring + ld_slot * STAGE;
         bf16* sB = sA + BM * BK;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
+            if (i < a_lo || i >= a_hi) continue;
             const int ih = a_h[i] + dh, iw = a_w[i] + dw;
             const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
                             static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
             const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.cs + ld_c0 + kchunk_a;
             const bf16* src = ok ? p.A + off : p.zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + (wave * AI + i) * PR * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
+            if (i < b_lo || i >= b_hi) continue;
             const bf16* src = b_off[i] >= 0 ? p.B + static_cast<uint32_t>(b_off[i] + woff) : p.zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sB + (wave * BI + i) * PR * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
         }
+    };
+    auto issue_stage = [&]() {
+        issue_pieces(0, AI, 0, BI);
         ++ld_issued;
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
     };
@@ -488,7 +522,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         const bool live = tile < total_tiles;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int m = tile_m * BM + (wave * AI + i) * PR + lrow;
+            const int m = tile_m * BM + row_a(i) + lrow;
             if (live && m < p.M) {
                 const uint32_t img = fastdiv(m, p.div_ab);
                 const uint32_t rem = m - img * (p.OA * p.OB);
@@ -504,7 +538,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int n = tile_n * BN + (wave * BI + i) * PR + lrow;
+            const int n = tile_n * BN + row_b(i) + lrow;
             if (live && n < p.N) {
                 b_cur[i] = p.B + static_cast<size_t>(n) * p.ldb + p.tap_woff[0] + kchunk;
                 b_step[i] = BK;
@@ -514,19 +548,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             }
         }
     };
-    auto plain_issue = [&]() {
+    auto plain_pieces = [&](int a_lo, int a_hi, int b_lo, int b_hi) {
         bf16* sA = ring + ld_slot * STAGE;
         bf16* sB = sA + BM * BK;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)a_cur[i], (lds_void_t*)(sA + (wave * AI + i) * PR * BK), 16, 0, 0);
+            if (i < a_lo || i >= a_hi) continue;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)a_cur[i], (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
             a_cur[i] += a_step[i];
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)b_cur[i], (lds_void_t*)(sB + (wave * BI + i) * PR * BK), 16, 0, 0);
+            if (i < b_lo || i >= b_hi) continue;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)b_cur[i], (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
             b_cur[i] += b_step[i];
         }
+    };
+    auto plain_issue = [&]() {
+        plain_pieces(0, AI, 0, BI);
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
     };
     auto plain_advance = [&]() {
@@ -614,7 +653,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
     };
 
-    if constexpr (PLAIN) {
+    // ---- ping-pong schedule: staging units in the order they are read (A lower halves, B lower halves, B upper halves,
+    // A upper halves of a K-step), one unit per phase; after the last unit of a K-step the cursor moves on
+    auto pp_unit = [&](int r) {
+        const int a_lo = r == 0 ? 0 : (r == 3 ? 2 : 0), a_hi = r == 0 ? 2 : (r == 3 ? 4 : 0);
+        const int b_lo = r == 1 ? 0 : (r == 2 ? 2 : 0), b_hi = r == 1 ? 2 : (r == 2 ? 4 : 0);
+        if constexpr (PLAIN) plain_pieces(a_lo, a_hi, b_lo, b_hi);
+        else issue_pieces(a_lo, a_hi, b_lo, b_hi);
+        if (r == 3) {
+            ld_slot ^= 1;
+            if constexpr (PLAIN) plain_advance();
+            else advance_cursor();
+        }
+    };
+    if constexpr (PP) {
+        if constexpr (PLAIN) plain_tile(first);
+        else loader_tile(first);
+        // six units ahead: the whole first K-step and the first two units of the second
+        pp_unit(0); pp_unit(1); pp_unit(2); pp_unit(3); pp_unit(0); pp_unit(1);
+        // four units (two DMA instructions each per wave) may stay in flight: the first two have landed
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if (wm == 1) asm volatile("s_barrier" ::: "memory");  // wave row 1 runs one barrier behind row 0 from here on
+    } else if constexpr (PLAIN) {
         plain_tile(first);
 #pragma unroll
         for (int k = 0; k < NS - 1; ++k) {
@@ -640,6 +700,67 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        if constexpr (PP) {
+            for (int s = 0; s < nsteps; ++s, ++g) {
+                const bf16* sA = ring + slot * STAGE;
+                const bf16* sB = sA + BM * BK;
+                bf16x8 fa[2][4], fbl[2][2], fbh[2][2];
+                auto read_a = [&](int half) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = wm * TM + (half * 4 + i) * 16 + (lane & 15);
+                            fa[kk][i] = *reinterpret_cast<const bf16x8*>(sA + row * BK + (((kk * 4 + (lane >> 4)) ^ swz(row)) << 3));
+                        }
+                };
+                auto read_b = [&](int half, bf16x8(&fb)[2][2]) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int row = wn * TN + (half * 2 + j) * 16 + (lane & 15);
+                            fb[kk][j] = *reinterpret_cast<const bf16x8*>(sB + row * BK + (((kk * 4 + (lane >> 4)) ^ swz(row)) << 3));
+                        }
+                };
+                // One phase: [this phase's fragment reads and DMA unit were issued by the caller] -> counted wait that
+                // retires the unit the next phase reads -> barrier -> 16 MFMAs of one output quadrant -> barrier.
+                auto mfma_quadrant = [&](int ih, int jh, bf16x8(&fb)[2][2]) {
+                    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[ih * 4 + i][jh * 2 + j] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_barrier" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // phase 1: lower A rows x lower B columns
+                pp_unit(2);
+                read_b(0, fbl);
+                read_a(0);
+                mfma_quadrant(0, 0, fbl);
+                // phase 2: lower A rows x upper B columns
+                pp_unit(3);
+                read_b(1, fbh);
+                mfma_quadrant(0, 1, fbh);
+                // phase 3: upper A rows x upper B columns
+                pp_unit(0);
+                read_a(1);
+                mfma_quadrant(1, 1, fbh);
+                // phase 4: upper A rows x lower B columns (fragments already in registers)
+                pp_unit(1);
+                mfma_quadrant(1, 0, fbl);
+                slot ^= 1;
+            }
+        } else
         for (int s = 0; s < nsteps; ++s, ++g) {
             if constexpr (PLAIN) {
                 // NS - 1 stages are always in flight here (the loader never stops issuing)
@@ -659,6 +780,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
 
         // ---- epilogue (wave-private): 16 rows at a time -> bf16 -> LDS -> 16-byte row segments
+        if constexpr (PP) {
+            // Both wave rows write their part of the tile at the same time: row 0 gives up its one-barrier lead here
+            // (this barrier pairs with the last barrier of row 1's K-loop) and row 1 falls back behind it after the
+            // epilogue.  Left one barrier apart, each row would wait at its next barrier for the other's whole epilogue.
+            if (wm == 0) asm volatile("s_barrier" ::: "memory");
+        }
         if (n0 != stats_n0) {
             flush_stats();
             stats_n0 = n0;
@@ -752,7 +879,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(yv[ps][e])));
                     }
-                    if (p.out_nt) {
+                    if (p.out_nt == 2) {
+                        // (measurement aid: no output store at all, see pdt_set_out_nt_bytes)
+                    } else if (p.out_nt) {
                         // the empty statements keep the optimizer from merging the two branches' stores into one plain
                         // store (which loses the cache policy)
                         asm volatile("" ::: "memory");
@@ -819,8 +948,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 }
             }
         }
+        if constexpr (PP) {
+            if (wm == 1) asm volatile("s_barrier" ::: "memory");  // row 1 is one barrier behind row 0 again
+        }
     }
     flush_stats();
+    if constexpr (PP) {
+        if (wm == 0) asm volatile("s_barrier" ::: "memory");  // pairs with the last barrier of wave row 1
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing stages
 }
 
@@ -835,23 +970,23 @@ static int pdt_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP>
 static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream);
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PP = false>
 static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stream) {
     // one tap at (0, 0), in bounds for every output pixel: the pointer-walking loader applies
     const bool plain = a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && (a.OA - 1) * a.istr < a.Hin && (a.OB - 1) * a.istr < a.Win;
-    if (plain) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, true>(a, stream);
-    return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, false>(a, stream);
+    if (plain) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, true, PP>(a, stream);
+    return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, false, PP>(a, stream);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP>
 static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream) {
     if ((a.C % BK) != 0) return -1;
     constexpr size_t lds = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
-    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK, PLAIN>;
+    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK, PLAIN, PP>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -866,13 +1001,13 @@ static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t st
     return pdt_launch_status();
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK>
+template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK, bool PP = false>
 static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
     if (a.zeros == nullptr) return -1;
     if (a.act != 0) {
         if (a.bn_y != nullptr || a.addend != nullptr || a.stats != nullptr) return -1;
-        if (a.act == 1 && a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 33, BK>(a, stream);
-        if (a.act == 2 && a.bias == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 16, BK>(a, stream);
+        if (a.act == 1 && a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 33, BK, PP>(a, stream);
+        if (a.act == 2 && a.bias == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 16, BK, PP>(a, stream);
         return -1;
     }
     if (a.bn_y != nullptr) {
@@ -881,19 +1016,20 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
         if (a.bias != nullptr || a.stats == nullptr || a.bn_consts == nullptr || a.stat_rows != 3) return -1;
         if (a.bn_y2 != nullptr) {
             if (a.addend == nullptr || a.bn_bits == nullptr || a.bn_consts2 == nullptr) return -1;
-            return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 74, BK>(a, stream);
+            return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 74, BK, PP>(a, stream);
         }
-        if (a.addend != nullptr && a.bn_bits != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 10, BK>(a, stream);
-        if (a.addend == nullptr && a.bn_bits == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 4, BK>(a, stream);
+        if (a.addend != nullptr && a.bn_bits != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 10, BK, PP>(a, stream);
+        if (a.addend == nullptr && a.bn_bits == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 4, BK, PP>(a, stream);
         return -1;
     }
-    if (a.bias != nullptr && a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 3, BK>(a, stream);
-    if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1, BK>(a, stream);
-    if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2, BK>(a, stream);
-    return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK>(a, stream);
+    if (a.bias != nullptr && a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 3, BK, PP>(a, stream);
+    if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1, BK, PP>(a, stream);
+    if (a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 2, BK, PP>(a, stream);
+    return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK, PP>(a, stream);
 }
 
-// Outputs of at least this many bytes are written with non-temporal stores by the ring kernels.
+// Outputs of at least this many bytes are written with non-temporal stores by the ring kernels.  A negative value is a
+// measurement aid: the ring kernels then skip the output store altogether (what the epilogue's stores cost a launch).
 static long long g_out_nt_bytes = 64ll << 20;
 PDT_API void pdt_set_out_nt_bytes(long long bytes) { g_out_nt_bytes = bytes; }
 
@@ -931,7 +1067,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     if (bn_y2 != nullptr && bn_y == nullptr) return -1;
     a.stat_rows = bn_y != nullptr ? 3 : 2;
     a.act = act;
-    a.out_nt = static_cast<long long>(M) * N * 2 >= g_out_nt_bytes;
+    a.out_nt = g_out_nt_bytes < 0 ? 2 : (static_cast<long long>(M) * N * 2 >= g_out_nt_bytes);
     a.out2 = static_cast<bf16*>(out2);
     a.act_src = static_cast<const bf16*>(act_src);
     if (bn_y != nullptr && (smallc || tile < 10)) return -1;  // only the ring kernels have this epilogue
@@ -978,6 +1114,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         case 14: return launch_gather_gemm_ring<256, 64, 8, 1, 3>(a, s);   // narrow N, 32x64 per wave
         case 15: return launch_gather_gemm_ring<512, 64, 8, 1, 2>(a, s);   // narrow N, 64x64 per wave: half the weight-fragment reads per FLOP
         case 16: return launch_gather_gemm_ring<256, 256, 2, 4, 2, 64>(a, s);  // 128x64 per wave, K-step 64, 2 stages
+        case 17: return launch_gather_gemm_ring<256, 256, 2, 4, 2, 64, true>(a, s);  // the same tile on the ping-pong schedule
         default: return -1;
     }
 }

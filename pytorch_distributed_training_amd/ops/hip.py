@@ -412,6 +412,12 @@ _RING_MIN_TILES = int(_os.environ.get("PDT_GEMM_RING_MIN_TILES", "768"))
 # flight, so they run on the 256x128 tile (two groups of operands requested ahead): -1.1 ms per ResNet-50 step.  (The
 # launches that only take sums with a recomputed mask are faster on the 256x256 tile.)
 _TILE_FUSED_TAIL = int(_os.environ.get("PDT_GEMM_TILE_FUSED_TAIL", "13"))
+# Single-tap 256x256 launches with at least eight K-steps run on the ping-pong schedule (tile 17: the wave rows of a
+# workgroup alternate between MFMA and LDS / DMA phases): +5-15 % on linear layers (bench/pp_check.py).  Multi-tap
+# launches (3x3 convolutions) stay on tile 16: their loader's address arithmetic hides better under a wave's own MFMAs
+# (ResNet-50 3x3 layers ran 8-12 % slower on the ping-pong schedule), and launches with one or two K-steps per tile are
+# bound by their stores either way.  0 switches the schedule off.
+_GEMM_PP = int(_os.environ.get("PDT_GEMM_PP", "1"))
 
 
 _ZERO_PAGES: dict = {}
@@ -488,6 +494,8 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
     tile = _pick_tile(M, N, len(taps) * max(C // 64, 1))
     if _TILE_FUSED_TAIL >= 0 and bn_bits is not None and tile == 16:
         tile = _TILE_FUSED_TAIL
+    if tile == 16 and _GEMM_PP and (_GEMM_PP > 1 or (len(taps) == 1 and C >= 512)):
+        tile = 17
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
                      ldb, ldo, C, len(taps),
