@@ -130,7 +130,7 @@ template <int NV>
 __global__ __launch_bounds__(512) void ce_fused_row_kernel(const bf16* __restrict__ logits, const long long* __restrict__ labels,
                                                           float* __restrict__ row_loss, bf16* __restrict__ dlogits,
                                                           int rows, int classes, long long ld_row, long long ld_drow,
-                                                          int pad_to) {
+                                                          int pad_to, float inv_rows) {
     __shared__ float red[16];
     const int row = blockIdx.x;
     const bf16* x = logits + row * ld_row;
@@ -174,7 +174,9 @@ __global__ __launch_bounds__(512) void ce_fused_row_kernel(const bf16* __restric
     const float l = m + __logf(s);
     if (threadIdx.x == 0) row_loss[row] = valid ? l - xy : 0.f;
     if (dlogits == nullptr) return;
-    const float g = valid ? 1.f / rows : 0.f;
+    // (dlogits may be the logits buffer itself: every thread has its part of the row in registers by now, and the
+    // block reductions above are barriers between the last load and the first store)
+    const float g = valid ? inv_rows : 0.f;
     const float ll2 = l * 1.4426950408889634f;
     bf16* d = dlogits + row * ld_drow;
     const int pvec = pad_to >> 3;
@@ -261,13 +263,68 @@ PDT_API int pdt_softmax_ce_fused(const void* logits, const long long* labels, fl
     const int need = (((dlogits != nullptr ? pad_to : c8) >> 3) + 511) / 512;
     const bf16* x = static_cast<const bf16*>(logits);
     bf16* d = static_cast<bf16*>(dlogits);
-#define PDT_CE(NV) hipLaunchKernelGGL(ce_fused_row_kernel<NV>, dim3(rows), dim3(512), 0, s, x, labels, row_loss, d, rows, classes, ld_row, ld_drow, pad_to)
+#define PDT_CE(NV) hipLaunchKernelGGL(ce_fused_row_kernel<NV>, dim3(rows), dim3(512), 0, s, x, labels, row_loss, d, rows, classes, ld_row, ld_drow, pad_to, 1.f / rows)
     if (need <= 4) PDT_CE(4);
     else if (need <= 8) PDT_CE(8);
     else if (need <= 13) PDT_CE(13);
     else PDT_CE(16);
 #undef PDT_CE
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, row_loss, loss, static_cast<long long>(rows), 1.f / rows);
+    return pdt_launch_status();
+}
+
+// The same pass over one chunk of `rows` rows of a batch of `total_rows` rows: the gradient is scaled by
+// 1 / total_rows and no mean is taken (pdt_mean_f32 over the row losses of all chunks does that).  `dlogits` may be
+// the logits buffer itself (in-place): a language-model head then needs no second [rows, vocabulary] buffer.
+PDT_API int pdt_softmax_ce_fused_chunk(const void* logits, const long long* labels, float* row_loss, void* dlogits,
+                                       int rows, int classes, long long ld_row, long long ld_drow, int pad_to,
+                                       long long total_rows, void* stream) {
+    const int c8 = (classes + 7) / 8 * 8;
+    if (rows <= 0 || total_rows < rows || classes <= 1024 || classes > 65536 || (ld_row % 8) != 0 || ld_row < c8) return -1;
+    if (dlogits != nullptr && ((ld_drow % 8) != 0 || (pad_to % 8) != 0 || pad_to < c8 || ld_drow < pad_to || pad_to > 65536)) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int need = (((dlogits != nullptr ? pad_to : c8) >> 3) + 511) / 512;
+    const bf16* x = static_cast<const bf16*>(logits);
+    bf16* d = static_cast<bf16*>(dlogits);
+    const float inv = 1.f / static_cast<float>(total_rows);
+#define PDT_CE(NV) hipLaunchKernelGGL(ce_fused_row_kernel<NV>, dim3(rows), dim3(512), 0, s, x, labels, row_loss, d, rows, classes, ld_row, ld_drow, pad_to, inv)
+    if (need <= 4) PDT_CE(4);
+    else if (need <= 8) PDT_CE(8);
+    else if (need <= 13) PDT_CE(13);
+    else PDT_CE(16);
+#undef PDT_CE
+    return pdt_launch_status();
+}
+
+// out[0] = scale * sum(x[0..n)) (deterministic, one workgroup)
+PDT_API int pdt_mean_f32(const float* x, float* out, long long n, float scale, void* stream) {
+    if (n <= 0) return -1;
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, out, n, scale);
+    return pdt_launch_status();
+}
+
+// dst += g[0] * src over fp32 vectors (n a multiple of 4): a gradient computed for an incoming gradient of 1 is
+// added to its destination once the incoming gradient is known
+__global__ __launch_bounds__(256) void axpy_dev_scalar_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                              const float* __restrict__ g, long long n4) {
+    const float gv = g[0];
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+        float4 d = dst[i];
+        const float4 a = src[i];
+        d.x += gv * a.x;
+        d.y += gv * a.y;
+        d.z += gv * a.z;
+        d.w += gv * a.w;
+        dst[i] = d;
+    }
+}
+
+PDT_API int pdt_axpy_dev_scalar_f32(float* dst, const float* src, const float* g, long long n, void* stream) {
+    if (n <= 0 || (n % 4) != 0) return -1;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpy_dev_scalar_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), g, n / 4);
     return pdt_launch_status();
 }
 

@@ -4,8 +4,8 @@ Not present in the reference (/root/reference/src/main.py:49 builds a ResNet-18 
 the large-gradient data-parallel workload (~355 M parameters, tied input/output
 embeddings) that stresses the bucket reducer and the fused AdamW step.
 The forward pass returns logits; with ``targets`` it returns the mean next-token
-cross-entropy computed by the fused softmax-cross-entropy kernel without materialising
-probabilities.
+cross-entropy from the fused output-projection + loss operator, which works through the rows
+in chunks and never materialises logits or probabilities for the whole batch.
 """
 
 from __future__ import annotations
@@ -53,10 +53,10 @@ class GPT2(nn.Module):
         for blk in self.h:
             x = blk(x)
         x = ops.layer_norm(x, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)
-        logits = ops.linear(x, self.wte.weight, None)  # tied output projection
         if targets is None:
-            return logits
-        return ops.softmax_cross_entropy(logits.view(b * s, -1), targets.reshape(-1))
+            return ops.linear(x, self.wte.weight, None)  # tied output projection
+        # projection + loss in one operator: the [b * s, vocabulary] logits are never held as a whole
+        return ops.lm_head_loss(x, self.wte.weight, targets)
 
 
 def gpt2_medium(vocab_size: int = 50257, n_ctx: int = 1024) -> GPT2:

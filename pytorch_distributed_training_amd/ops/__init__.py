@@ -16,6 +16,12 @@ import torch
 from . import reference as _ref
 
 
+import os as _os
+
+# 0: projection and loss as two operators with full-batch logits (A/B measurements; caps the batch at 42 x 1024 tokens)
+_LM_HEAD_FUSED = _os.environ.get("PDT_LM_HEAD_FUSED", "1") != "0"
+
+
 def _hip():
     from . import hip  # imported lazily: loading it maps the kernel library
 
@@ -105,6 +111,16 @@ def softmax_cross_entropy(logits, labels):
     if logits.is_cuda:
         return _hip().softmax_cross_entropy(logits, labels)
     return _ref.softmax_cross_entropy(logits, labels)
+
+
+def lm_head_loss(x, weight, labels):
+    """Mean cross-entropy of the logits ``x W^T`` (no bias) against ``labels``: a language model's tied output
+    projection and loss.  On GPU the rows are processed in chunks through one scratch buffer, so the
+    ``[rows, vocabulary]`` logits of the whole batch never exist (see ``ops.hip._LMHeadLoss``)."""
+    if x.is_cuda and 1024 < weight.shape[0] <= 65536 and _LM_HEAD_FUSED:
+        return _hip().lm_head_loss(x, weight, labels)
+    logits = linear(x, weight, None)
+    return softmax_cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1))
 
 
 def layer_norm(x, weight, bias, eps: float = 1e-5, link=None):

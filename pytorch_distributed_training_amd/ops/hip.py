@@ -59,6 +59,9 @@ _avgpool_bwd = _sig("pdt_avgpool_bwd", [_vp, _vp, _i, _i, _i, _vp])
 _ce_fwd = _sig("pdt_softmax_ce_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp])
 _ce_bwd = _sig("pdt_softmax_ce_bwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _i, _vp])
 _ce_fused = _sig("pdt_softmax_ce_fused", [_vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _vp])
+_ce_fused_chunk = _sig("pdt_softmax_ce_fused_chunk", [_vp, _vp, _vp, _vp, _i, _i, _ll, _ll, _i, _ll, _vp])
+_mean_f32 = _sig("pdt_mean_f32", [_vp, _vp, _ll, _f, _vp])
+_axpy_dev = _sig("pdt_axpy_dev_scalar_f32", [_vp, _vp, _vp, _ll, _vp])
 _scale_by_scalar = _sig("pdt_scale_by_scalar", [_vp, _vp, _ll, _vp])
 _nchw_to_nhwc = _sig("pdt_nchw_to_nhwc_bf16", [_vp, _vp, _i, _i, _i, _i, _i, _vp])
 _pad_pixels = _sig("pdt_pad_pixels", [_vp, _vp] + [_i] * 8 + [_vp])
@@ -1336,6 +1339,95 @@ class _SoftmaxCE(torch.autograd.Function):
 
 def softmax_cross_entropy(logits, labels):
     return _SoftmaxCE.apply(logits, labels)
+
+
+LM_HEAD_CHUNK_ROWS = int(_os.environ.get("PDT_LM_HEAD_CHUNK_ROWS", "32768"))
+
+
+class _LMHeadLoss(torch.autograd.Function):
+    """mean cross-entropy of ``x W^T`` against ``labels`` - a language model's output projection and loss - without
+    ever holding the ``[rows, vocabulary]`` logits (or their gradient) of the whole batch.
+
+    Rows are processed in chunks.  Per chunk: logits GEMM into a scratch buffer -> softmax-cross-entropy kernel that
+    turns the buffer into the logits' gradient in place (each row sits in the registers of one workgroup) -> the
+    data-gradient and weight-gradient GEMMs consume it.  So the forward pass already produces ``dx`` and ``dW`` for
+    an incoming gradient of 1; the backward pass multiplies them by the incoming gradient (a device scalar: no
+    host synchronisation) - ``dx`` in place, ``dW`` while adding it to the weight's gradient.  Peak memory is one
+    chunk (32768 x 50304 bf16 = 3.3 GB, the largest that 32-bit element offsets allow) instead of two full-batch
+    tensors (2 x 3.3 GB at 32 x 1024 tokens, impossible beyond
+    32-bit element offsets from 43 sequences on), at the same number of bytes moved."""
+
+    @staticmethod
+    def forward(ctx, x, weight, labels):
+        n, k = weight.shape
+        if k % 64 != 0:
+            raise ValueError("in_features must be a multiple of 64")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, k)
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        labels = labels.reshape(-1).to(torch.int64).contiguous()
+        if labels.numel() != M:
+            raise ValueError("labels and activations disagree on the number of rows")
+        if not (1024 < n <= 65536):
+            raise ValueError("the fused language-model head handles vocabularies of 1025 to 65536 entries")
+        dev = x.device
+        npad = _round_up(n, 64)
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        rows_c = min(M, max(256, LM_HEAD_CHUNK_ROWS))
+        scratch = torch.empty((rows_c, npad), dtype=torch.bfloat16, device=dev)
+        _check_size(scratch)
+        row_loss = torch.empty(M, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        wb = SHADOWS.fwd(weight)
+        dx = torch.empty((M, k), dtype=torch.bfloat16, device=dev) if want_dx else None
+        dw = torch.zeros((n, k), dtype=torch.float32, device=dev) if want_dw else None
+        wt = SHADOWS.dgrad(weight, 1)[0] if want_dx else None  # [k][npad]
+        one = [(0, 0, 0)]
+        for r0 in range(0, M, rows_c):
+            rows = min(rows_c, M - r0)
+            xc = x2[r0:r0 + rows]
+            _launch_gather_gemm(xc, wb, scratch, None, None, rows, n, k, npad, k, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+            grad_buf = scratch if (want_dx or want_dw) else None
+            _check(_ce_fused_chunk(scratch.data_ptr(), labels[r0:r0 + rows].data_ptr(), row_loss[r0:r0 + rows].data_ptr(),
+                                   _ptr(grad_buf), rows, n, npad, npad, npad, M, _stream()), "softmax_ce_fused_chunk")
+            if want_dx:
+                _launch_gather_gemm(scratch, wt, dx[r0:r0 + rows], None, None, rows, k, npad, k, npad, one, 1, 1, 1, 1, 1, 1, 1, 1,
+                                    0, 0)
+            if want_dw:
+                _launch_wgrad(scratch, xc, dw, rows, n, npad, k, one, k, 1, 1, 1, 1, 1)
+        _check(_mean_f32(row_loss.data_ptr(), loss.data_ptr(), M, 1.0 / M, _stream()), "mean")
+        ctx.grads = [dx, dw]
+        ctx.weight = weight
+        ctx.lead, ctx.k = lead, k
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, dw = ctx.grads
+        ctx.grads = [None, None]
+        if dx is None and dw is None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            raise RuntimeError("the fused language-model head handed its gradients out already (backward ran twice)")
+        g1 = g.reshape(1).to(torch.float32).contiguous()
+        gx = gw = None
+        if dx is not None:
+            _check(_scale_by_scalar(dx.data_ptr(), g1.data_ptr(), dx.numel(), _stream()), "scale_by_scalar")
+            gx = dx.reshape(*ctx.lead, ctx.k)
+        if dw is not None:
+            weight = ctx.weight
+            sink = _grad_sink(weight, tuple(weight.shape))
+            if sink is not None:
+                _check(_axpy_dev(sink.data_ptr(), dw.data_ptr(), g1.data_ptr(), dw.numel(), _stream()), "axpy")
+            else:
+                gw = dw * g1
+        return gx, gw, None
+
+
+def lm_head_loss(x, weight, labels):
+    return _LMHeadLoss.apply(x, weight, labels)
 
 
 # ------------------------------------------------------------------------------------------------

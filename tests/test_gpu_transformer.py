@@ -253,3 +253,32 @@ def test_fused_gelu_mlp_matches_the_composition(ht, rows, d, hd, res):
     assert _rel(ya, yb) < 1e-2
     for a, b in zip(got, [xb.grad, w1.grad, b1.grad, w2.grad, b2.grad]):
         assert _rel(a, b) < 1.5e-2
+
+
+@pytest.mark.parametrize("chunk,upstream", [(128, 1.0), (4096, 0.25)])
+def test_lm_head_loss_chunked_matches_fp32_reference(chunk, upstream):
+    """Output projection + cross-entropy in one operator, rows in chunks through one scratch buffer: loss, dx and dW
+    against fp32 PyTorch on the bf16-rounded operands (vocabulary 50257 as in GPT-2, not a multiple of 8)."""
+    from pytorch_distributed_training_amd.ops import hip
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    M, K, V = 300, 256, 50257
+    x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(V, K, device=dev) * 0.05).requires_grad_(True)
+    y = torch.randint(0, V, (M,), device=dev)
+    old = hip.LM_HEAD_CHUNK_ROWS
+    hip.LM_HEAD_CHUNK_ROWS = chunk
+    try:
+        loss = hip.lm_head_loss(x, w, y)
+        (loss * upstream).backward()
+    finally:
+        hip.LM_HEAD_CHUNK_ROWS = old
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    ref = F.cross_entropy(xr @ wr.t(), y)
+    (ref * upstream).backward()
+    assert abs(float(loss) - float(ref)) < 2e-3 * float(ref)
+    rel = lambda a, b: float((a.float() - b).norm() / (b.norm() + 1e-12))
+    assert rel(x.grad, xr.grad) < 2e-2
+    assert rel(w.grad, wr.grad) < 2e-2
