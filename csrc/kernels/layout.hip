@@ -33,6 +33,56 @@ PDT_API int pdt_nchw_to_nhwc_bf16(const void* x, void* out, int NB, int C, int H
     return pdt_launch_status();
 }
 
+// uint8 NHWC image batch (what decoders and image files hold) -> normalised bf16 NHWC:
+// out[i] = x[i] * scale[c] + shift[c], c = i mod 3.  A thread converts 8 pixels (24 bytes in, 48 bytes out), so the
+// channel of every element is known at compile time.  The host therefore ships one byte per element over PCIe
+// instead of four (fp32 NCHW), and ToTensor + Normalize + the layout change are this one pass on the GPU.
+struct U8Norm {
+    float scale[3];
+    float shift[3];
+};
+
+__global__ __launch_bounds__(256) void u8_rgb_to_bf16_kernel(const uint8_t* __restrict__ x, bf16* __restrict__ out, long long n24,
+                                                            long long tail_start, long long total, U8Norm nm) {
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < n24; v += gridDim.x * 256ll) {
+        const uint2* src = reinterpret_cast<const uint2*>(x + v * 24);
+        uint32_t w[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint2 t = src[i];
+            w[2 * i] = t.x;
+            w[2 * i + 1] = t.y;
+        }
+        bf16x8 o[3];
+#pragma unroll
+        for (int e = 0; e < 24; ++e) {
+            const float f = static_cast<float>((w[e >> 2] >> ((e & 3) * 8)) & 0xffu);
+            o[e >> 3][e & 7] = f32_to_bf16(f * nm.scale[e % 3] + nm.shift[e % 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<bf16x8*>(out + v * 24 + i * 8) = o[i];
+    }
+    // the last (total mod 24) elements, if any
+    for (long long i = tail_start + blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll)
+        out[i] = f32_to_bf16(static_cast<float>(x[i]) * nm.scale[i % 3] + nm.shift[i % 3]);
+}
+
+// x: [pixels][3] uint8 (8-byte aligned), out: [pixels][3] bf16 (16-byte aligned)
+PDT_API int pdt_u8_rgb_to_bf16(const void* x, void* out, long long pixels, const float* scale, const float* shift, void* stream) {
+    if (pixels <= 0 || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(out) & 15)) return -1;
+    U8Norm nm;
+    for (int c = 0; c < 3; ++c) {
+        nm.scale[c] = scale[c];
+        nm.shift[c] = shift[c];
+    }
+    const long long total = pixels * 3, n24 = total / 24;
+    long long g = (n24 + 255) / 256;
+    g = g < 1 ? 1 : (g > 16384 ? 16384 : g);
+    hipLaunchKernelGGL(u8_rgb_to_bf16_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint8_t*>(x),
+                       static_cast<bf16*>(out), n24, n24 * 24, total, nm);
+    return pdt_launch_status();
+}
+
 // Few-channel images for the packed-row convolution: out[n][hp][wp][0..CP) = x[n][hp - pad][wp - pad][0..C)
 // inside the image, zero on the border and in the padding channels (CP in {4, 8}; one 8- or 16-byte store
 // per pixel).  The convolution then reads whole kernel rows as contiguous, bounds-check-free vectors.

@@ -1,5 +1,6 @@
 from .datasets import CIFAR10, SyntheticImageDataset, SyntheticTokenDataset, build_dataset  # noqa: F401
 from .loader import (  # noqa: F401
+    BatchLoader,
     DevicePrefetcher,
     DeviceSyntheticLoader,
     build_loader,

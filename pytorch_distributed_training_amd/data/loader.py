@@ -1,15 +1,24 @@
 """Batch delivery to the device.
 
-The reference uploads every batch with a blocking ``.to(device)`` from pageable memory
-(/root/reference/src/main.py:61,69-70).  Here the host loader pins its batches and
-:class:`DevicePrefetcher` copies batch *k+1* on a separate HIP stream while step *k* runs;
-:class:`DeviceSyntheticLoader` keeps a fixed set of batches resident in HBM so throughput
-benchmarks measure the trainer, not the host.
+The reference uploads every batch with a blocking ``.to(device)`` from pageable memory, after a per-item
+``ToTensor`` in worker processes (/root/reference/src/main.py:44-47,61,69-70): four bytes per element cross
+PCIe and every image is touched several times on the host.  Here
+
+* :class:`BatchLoader` asks the dataset for whole batches (``get_batch``: one vectorised gather of raw uint8 HWC
+  images) from a few worker threads, straight into a ring of pinned buffers - no per-item Python, no pickling
+  between processes, one byte per element;
+* :class:`DevicePrefetcher` copies batch *k+1* on a separate HIP stream while step *k* runs and converts it there
+  (uint8 NHWC -> normalised bf16 NHWC, one kernel), so the training stream only waits for an event;
+* datasets without ``get_batch`` go through ``torch.utils.data.DataLoader`` (worker processes, pinned collation);
+* :class:`DeviceSyntheticLoader` keeps a fixed set of batches resident in HBM so throughput benchmarks measure
+  the trainer, not the host.
 """
 
 from __future__ import annotations
 
-from typing import Iterator, Optional, Tuple
+import queue
+import threading
+from typing import Iterator, List, Optional, Tuple
 
 import torch
 from torch.utils.data import DataLoader, Dataset
@@ -27,11 +36,13 @@ def build_loader(
     drop_last: bool = False,
     pin_memory: bool = False,
     seed: int = 0,
-) -> Tuple[DataLoader, ShardedSampler]:
+) -> Tuple[object, ShardedSampler]:
     """``batch_size`` is per process, as in the reference (main.py:61)."""
     # one sampler class for any world size (a single process is a one-replica shard): the order depends only on
     # (seed, epoch), and a pass can start behind the samples a resumed job has already seen
     sampler = ShardedSampler(dataset, world_size, rank, shuffle=shuffle, seed=seed, drop_last=drop_last)
+    if hasattr(dataset, "get_batch"):
+        return BatchLoader(dataset, batch_size, sampler, num_workers, drop_last, pin_memory), sampler
     loader = DataLoader(
         dataset,
         batch_size=batch_size,
@@ -45,12 +56,107 @@ def build_loader(
     return loader, sampler
 
 
-class DevicePrefetcher:
-    """Wraps a host loader; overlaps the H2D copy of the next batch with the current step."""
+class BatchLoader:
+    """Whole batches from a dataset with ``get_batch(indices, out) -> (uint8 [B, H, W, C], labels)``.
 
-    def __init__(self, loader, device: torch.device):
+    ``num_workers`` threads (at least one) each gather a batch into a buffer taken from a ring of pinned host
+    tensors; batches are delivered in sampler order.  The gather is a single ``index_select`` (it releases the
+    interpreter lock), so a handful of threads saturates host memory bandwidth where per-item loading would need
+    dozens of processes.  A buffer returns to the ring when the batch after the next one is requested, i.e. after
+    the consumer has had a full iteration to finish its (asynchronous) upload."""
+
+    def __init__(self, dataset, batch_size: int, sampler, num_workers: int = 2, drop_last: bool = False,
+                 pin_memory: bool = False):
+        self.dataset, self.batch_size, self.sampler = dataset, int(batch_size), sampler
+        self.workers = max(1, int(num_workers))
+        self.drop_last = drop_last
+        self.pin = bool(pin_memory) and torch.cuda.is_available()
+        self._ring: List[torch.Tensor] = []
+
+    def __len__(self) -> int:
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _buffers(self, shape, dtype, count: int) -> "queue.Queue":
+        if len(self._ring) != count or self._ring[0].shape != shape or self._ring[0].dtype != dtype:
+            self._ring = [torch.empty(shape, dtype=dtype, pin_memory=self.pin) for _ in range(count)]
+        q: "queue.Queue" = queue.Queue()
+        for b in self._ring:
+            q.put(b)
+        return q
+
+    def __iter__(self) -> Iterator:
+        idx = torch.tensor(list(iter(self.sampler)), dtype=torch.int64)
+        bs = self.batch_size
+        starts = list(range(0, len(idx) - (bs - 1 if self.drop_last else 0), bs)) if len(idx) else []
+        if not starts:
+            return
+        probe, _ = self.dataset.get_batch(idx[:1])
+        shape = (bs,) + tuple(probe.shape[1:])
+        depth = self.workers + 3  # in flight in the workers + the two batches the consumer may still be using
+        free = self._buffers(shape, probe.dtype, depth)
+        results = {}
+        cond = threading.Condition()
+        todo: "queue.Queue" = queue.Queue()
+        for k, s0 in enumerate(starts):
+            todo.put((k, s0))
+        stop = threading.Event()
+        errors: List[BaseException] = []
+
+        def work():
+            while not stop.is_set():
+                try:
+                    k, s0 = todo.get_nowait()
+                except queue.Empty:
+                    return
+                sel = idx[s0:s0 + bs]
+                buf = free.get()
+                try:
+                    out = buf if len(sel) == bs else buf[: len(sel)]
+                    imgs, labels = self.dataset.get_batch(sel, out=out)
+                except BaseException as e:  # surfaced in the consumer
+                    errors.append(e)
+                    imgs, labels = None, None
+                with cond:
+                    results[k] = (imgs, labels, buf)
+                    cond.notify_all()
+
+        # workers take batch numbers in order, so holding `depth` buffers bounds how far they run ahead
+        threads = [threading.Thread(target=work, name=f"pdt-loader-{i}", daemon=True) for i in range(self.workers)]
+        for t in threads:
+            t.start()
+        held: List[torch.Tensor] = []
+        try:
+            for k in range(len(starts)):
+                with cond:
+                    while k not in results:
+                        cond.wait(timeout=1.0)
+                    imgs, labels, buf = results.pop(k)
+                if errors:
+                    raise errors[0]
+                held.append(buf)
+                if len(held) > 2:
+                    free.put(held.pop(0))
+                yield imgs, labels
+        finally:
+            stop.set()
+            for b in held:
+                free.put(b)
+            for _ in threads:  # unblock workers waiting for a buffer
+                free.put(self._ring[0])
+            for t in threads:
+                t.join(timeout=5)
+
+
+class DevicePrefetcher:
+    """Wraps a host loader; overlaps the H2D copy of the next batch - and, for raw uint8 image batches, their
+    conversion to the models' input form - with the current step.  ``convert(images_on_device) -> tensor`` runs on
+    the copy stream right behind the upload."""
+
+    def __init__(self, loader, device: torch.device, convert=None):
         self.loader = loader
         self.device = torch.device(device)
+        self.convert = convert
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def __len__(self) -> int:
@@ -58,9 +164,15 @@ class DevicePrefetcher:
 
     def _upload(self, batch):
         if self.stream is None:
-            return tuple(t.to(self.device) for t in batch)
+            out = tuple(t.to(self.device) for t in batch)
+            return (self.convert(out[0]),) + out[1:] if (self.convert and out[0].dtype == torch.uint8) else out
         with torch.cuda.stream(self.stream):
-            return tuple(t.to(self.device, non_blocking=True) for t in batch)
+            out = tuple(t.to(self.device, non_blocking=True) for t in batch)
+            if self.convert is not None and out[0].dtype == torch.uint8:
+                raw = out[0]
+                out = (self.convert(raw),) + out[1:]
+                raw.record_stream(self.stream)
+            return out
 
     def __iter__(self) -> Iterator:
         it = iter(self.loader)

@@ -174,3 +174,18 @@ def to_device_layout(x, dtype=torch.bfloat16):
     if x.is_cuda:
         return _hip().to_device_layout(x, dtype)
     return x.to(dtype)
+
+
+def image_batch_to_device_layout(x, dtype=torch.bfloat16, mean=None, std=None):
+    """uint8 ``[N, H, W, 3]`` batch (the form images travel in) -> float batch the models read: normalised
+    ``(x / 255 - mean) / std``, logical NCHW.  On GPU one kernel produces bf16 NHWC; on CPU plain PyTorch."""
+    if x.is_cuda:
+        if dtype != torch.bfloat16:
+            raise ValueError("GPU kernels compute in bf16")
+        return _hip().u8_to_device_layout(x, mean, std)
+    out = x.permute(0, 3, 1, 2).to(torch.float32).contiguous().div_(255.0)  # plain NCHW, as ToTensor + default collation give
+    if mean is not None or std is not None:
+        m = torch.tensor(mean or (0.0, 0.0, 0.0), dtype=torch.float32).view(1, 3, 1, 1)
+        s_ = torch.tensor(std or (1.0, 1.0, 1.0), dtype=torch.float32).view(1, 3, 1, 1)
+        out = (out - m) / s_
+    return out.to(dtype)

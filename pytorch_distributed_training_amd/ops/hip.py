@@ -64,6 +64,7 @@ _mean_f32 = _sig("pdt_mean_f32", [_vp, _vp, _ll, _f, _vp])
 _axpy_dev = _sig("pdt_axpy_dev_scalar_f32", [_vp, _vp, _vp, _ll, _vp])
 _scale_by_scalar = _sig("pdt_scale_by_scalar", [_vp, _vp, _ll, _vp])
 _nchw_to_nhwc = _sig("pdt_nchw_to_nhwc_bf16", [_vp, _vp, _i, _i, _i, _i, _i, _vp])
+_u8_rgb_to_bf16 = _sig("pdt_u8_rgb_to_bf16", [_vp, _vp, _ll, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _vp])
 _pad_pixels = _sig("pdt_pad_pixels", [_vp, _vp] + [_i] * 8 + [_vp])
 _cast_pad = _sig("pdt_cast_pad_f32_bf16", [_vp, _vp, _ll, _i, _i, _vp])
 _transpose_w = _sig("pdt_transpose_w", [_vp, _vp, _i, _i, _i, _vp])
@@ -251,6 +252,21 @@ def to_device_layout(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     _check(_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), n, c, h, w, 0 if x.dtype == torch.float32 else 1, _stream()),
            "nchw_to_nhwc")
     return out
+
+
+def u8_to_device_layout(x: torch.Tensor, mean=None, std=None) -> torch.Tensor:
+    """uint8 ``[N, H, W, 3]`` image batch on the GPU -> bf16 NHWC (logical NCHW, channels_last) with
+    ``(x / 255 - mean) / std`` per channel (``ToTensor`` alone when ``mean`` / ``std`` are not given)."""
+    if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[-1] != 3 or not x.is_contiguous():
+        raise ValueError("expected a contiguous uint8 [N, H, W, 3] batch")
+    n, h, w, _ = x.shape
+    mean = tuple(mean) if mean is not None else (0.0, 0.0, 0.0)
+    std = tuple(std) if std is not None else (1.0, 1.0, 1.0)
+    scale = (ctypes.c_float * 3)(*[1.0 / (255.0 * s_) for s_ in std])
+    shift = (ctypes.c_float * 3)(*[-m / s_ for m, s_ in zip(mean, std)])
+    out = torch.empty((n, h, w, 3), dtype=torch.bfloat16, device=x.device)
+    _check(_u8_rgb_to_bf16(x.data_ptr(), out.data_ptr(), n * h * w, scale, shift, _stream()), "u8_rgb_to_bf16")
+    return out.permute(0, 3, 1, 2)
 
 
 # ------------------------------------------------------------------------------------------------

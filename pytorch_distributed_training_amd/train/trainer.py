@@ -113,8 +113,11 @@ def resolve_dtype(cfg: TrainConfig, device: torch.device) -> torch.dtype:
 
 
 def prepare_image_batch(x: torch.Tensor, device: torch.device, dtype: torch.dtype) -> torch.Tensor:
-    """Device placement, compute dtype and (on GPU) NHWC layout for an NCHW float batch."""
+    """Device placement, compute dtype and (on GPU) NHWC layout for an image batch: raw uint8 ``[N, H, W, 3]``
+    (scaled to [0, 1], the effect of the reference's ``ToTensor``, main.py:44-47) or NCHW float."""
     x = x.to(device=device, non_blocking=True)
+    if x.dtype == torch.uint8:
+        return ops.image_batch_to_device_layout(x, dtype)
     if device.type == "cuda":
         return ops.to_device_layout(x, dtype)
     return x.to(dtype)
@@ -143,6 +146,7 @@ class Trainer:
         self.dataset, self.data_desc = build_dataset(
             cfg.dataset, cfg.data_dir, self.kind, self.image_size, self.num_classes,
             cfg.dataset_length or None, cfg.seq_len, vocab or 50257, train=cfg.train_split, seed=cfg.seed,
+            wait_for_main=(self.env.is_main, lambda: barrier(self.env)) if self.env.distributed else None,
         )
         if self.kind == "image" and hasattr(self.dataset, "classes") and not cfg.num_classes:
             self.num_classes = len(self.dataset.classes)  # main.py:49
@@ -218,7 +222,7 @@ class Trainer:
             shuffle=cfg.shuffle, drop_last=cfg.drop_last, pin_memory=self.device.type == "cuda", seed=cfg.seed,
         )
         if self.device.type == "cuda":
-            loader = DevicePrefetcher(loader, self.device)
+            loader = DevicePrefetcher(loader, self.device, convert=lambda u8: ops.image_batch_to_device_layout(u8, self.dtype))
         return loader, sampler
 
     # ------------------------------------------------------------------ one step
@@ -463,7 +467,10 @@ class Trainer:
         env = self.env
         was_training = self.model.training
         self.model.eval()
-        loader, _ = build_loader(self.dataset, self.cfg.batch_size, 0, env.rank, env.world_size, shuffle=False)
+        loader, _ = build_loader(self.dataset, self.cfg.batch_size, self.cfg.num_workers, env.rank, env.world_size,
+                                 shuffle=False, pin_memory=self.device.type == "cuda")
+        if self.device.type == "cuda":  # uploads (and uint8 -> bf16 conversion) of batch k+1 overlap batch k
+            loader = DevicePrefetcher(loader, self.device, convert=lambda u8: ops.image_batch_to_device_layout(u8, self.dtype))
         tot = torch.zeros(3, dtype=torch.float64, device=self.device)  # loss_sum, correct, count
         for batch in loader:
             if self.kind == "lm":
@@ -475,7 +482,9 @@ class Trainer:
             else:
                 imgs, lbls = batch
                 lbls = lbls.to(self.device)
-                preds = self.raw_model(prepare_image_batch(imgs, self.device, self.dtype))
+                if imgs.device != self.device or imgs.dtype != self.dtype:
+                    imgs = prepare_image_batch(imgs, self.device, self.dtype)
+                preds = self.raw_model(imgs)
                 loss = ops.softmax_cross_entropy(preds, lbls)
                 n = lbls.shape[0]
                 tot[0] += loss.double() * n

@@ -696,3 +696,19 @@ def test_transposed_weight_copies_are_rebuilt_in_one_launch_after_the_optimizer_
             n, c = mat.shape[0], mat.shape[1] // taps
             ref = mat.view(n, taps, c).permute(2, 1, 0).reshape(c, taps * n).to(torch.bfloat16)
             assert npad == n and torch.equal(wt, ref)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7), (16, 224, 224), (2, 32, 32)])
+def test_u8_image_batch_to_bf16_nhwc(shape):
+    """uint8 NHWC -> normalised bf16 NHWC in one kernel, against (x / 255 - mean) / std in fp32."""
+    from pytorch_distributed_training_amd import ops
+
+    n, h, w = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, generator=g)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for m, s in ((None, None), (mean, std)):
+        out = ops.image_batch_to_device_layout(x.cuda(), torch.bfloat16, m, s)
+        assert out.shape == (n, 3, h, w) and out.is_contiguous(memory_format=torch.channels_last) or n * h * w < 8
+        ref = ops.image_batch_to_device_layout(x, torch.float32, m, s)
+        assert torch.equal(out.float().cpu(), ref.to(torch.bfloat16).float())

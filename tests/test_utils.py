@@ -113,3 +113,58 @@ def test_device_synthetic_loader_cycles():
     ld = DeviceSyntheticLoader(lambda i: (torch.full((2,), i), torch.zeros(2)), steps=5, n_resident=2)
     assert len(ld) == 5
     assert [int(x[0]) for x, _ in ld] == [0, 1, 0, 1, 0]
+
+
+def test_batch_loader_delivers_vectorised_uint8_batches_in_order(tmp_path):
+    import numpy as np
+
+    from pytorch_distributed_training_amd.data import BatchLoader, build_loader
+
+    ds = SyntheticImageDataset(length=37, image_size=8, num_classes=5, seed=1)
+    loader, sampler = build_loader(ds, batch_size=8, num_workers=3, rank=1, world_size=2, shuffle=True, seed=4)
+    assert isinstance(loader, BatchLoader) and len(loader) == 3  # ceil(19 / 8): rank 1 holds 19 of the padded 38
+    sampler.set_epoch(2)
+    want = list(iter(sampler))
+    for _pass in range(2):  # buffers are recycled between passes
+        sampler.set_epoch(2)
+        seen = []
+        for k, (imgs, labels) in enumerate(loader):
+            assert imgs.dtype == torch.uint8 and imgs.shape[1:] == (8, 8, 3)
+            idx = torch.tensor(want[k * 8:(k + 1) * 8])
+            ref_imgs, ref_labels = ds.get_batch(idx)
+            assert torch.equal(imgs, ref_imgs) and torch.equal(labels, ref_labels)
+            # the per-item path (what the reference's transform yields) describes the same data
+            item, lab = ds[int(idx[0])]
+            assert torch.allclose(item, imgs[0].permute(2, 0, 1).float() / 255) and lab == int(labels[0])
+            seen += idx.tolist()
+        assert seen == want
+
+
+def test_cifar10_python_batches_are_read_without_executing_pickle_code(tmp_path):
+    import pickle
+
+    import numpy as np
+    import pytest
+
+    d = tmp_path / "cifar-10-batches-py"
+    d.mkdir()
+    data = np.arange(4 * 3072, dtype=np.uint8).reshape(4, 3072)
+    with open(d / "test_batch", "wb") as f:
+        pickle.dump({"data": data, "labels": [1, 2, 3, 4], "filenames": ["a", "b", "c", "d"]}, f, protocol=2)
+    ds = CIFAR10(str(tmp_path), train=False)
+    assert len(ds) == 4 and ds.data.shape == (4, 32, 32, 3)
+    img, lab = ds[2]
+    assert lab == 3 and torch.equal((img * 255).round().to(torch.uint8), torch.from_numpy(data[2].reshape(3, 32, 32)))
+    imgs, labels = ds.get_batch(torch.tensor([3, 0]))
+    assert imgs.shape == (2, 32, 32, 3) and labels.tolist() == [4, 1]
+
+    class Evil:
+        def __reduce__(self):
+            import os
+
+            return (os.system, ("echo pwned > /dev/null",))
+
+    with open(d / "test_batch", "wb") as f:
+        pickle.dump({"data": data, "labels": [1, 2, 3, 4], "x": Evil()}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError):
+        CIFAR10(str(tmp_path), train=False)
