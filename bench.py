@@ -248,7 +248,7 @@ def main():
     shutdown(env)
 
 
-STOCK_PER_GPU = {"resnet50": 6510.2, "vit_b_16": 3688.0, "gpt2_medium": 194240.0}
+STOCK_PER_GPU = {"resnet50": 6888.2, "vit_b_16": 4073.8, "gpt2_medium": 194240.0}
 
 
 def collect_extras(extras, args, env, model, raw, step, sync, zero_grad, elapsed, on_gpu, dev):

@@ -48,6 +48,10 @@ struct GatherGemmArgs {
     int stat_rows;             // rows per slot of `stats`: 2 (forward statistics) or 3 (backward sums)
     // activation fused into the epilogue: 1 = also store gelu(result) to out2 (Out keeps the pre-activation for the
     // backward pass); 2 = multiply the result by gelu'(act_src), act_src being that pre-activation (layout of Out)
+    // ring variant, single-tap launches: the A operand is relu(A * scale[k] + shift[k]) per input channel k, i.e. the
+    // BatchNorm + ReLU of the layer before this convolution applied to its raw output on the way in (xf = that
+    // BatchNorm's [4][C] constants: mean, rstd, scale, shift).  The normalised activation tensor is never written.
+    const float* xf;
     int act;
     int out_nt;  // ring variant: store the result rows non-temporally (outputs far larger than the caches; +2-3 % on
                  // the bandwidth-bound 1x1 layers of a 2048-image ResNet-50 step)
@@ -380,9 +384,16 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // both waves of a SIMD read at the same time and then both compete for the matrix pipe).  Operands are staged in
 // units of 128 rows (the rows of one phase: the lower or upper half of every wave's A rows or B columns), one unit
 // per phase, six units ahead of the reads, with a counted wait that leaves four units in flight across the barriers.
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK, bool PLAIN = false, bool PP = false>
+//
+// XF (single-tap launches on the two-stage tiles): BatchNorm + ReLU of the producing layer applied to the A operand.
+// A stage is transformed in place in LDS right after it has landed - every thread rewrites four 16-byte chunks with
+// the per-channel scale / shift read from a table in LDS - followed by a second barrier, so each element is
+// transformed once per tile (doing it on the MFMA fragments would repeat the arithmetic in all four waves of a wave
+// row).  These launches are bound by their output stores; the extra LDS pass and barrier hide behind them.
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK, bool PLAIN = false, bool PP = false, bool XF = false>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const GatherGemmArgs p) {
     constexpr int NW = WM * WN;
+    static_assert(!XF || (PLAIN && !PP && BK == 64), "operand transform: single-tap launches on the plain ring schedule");
     static_assert(!PP || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64), "ping-pong schedule: 256x256, 2x4 waves");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
@@ -404,6 +415,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     bf16* epi = ring + NS * STAGE + wave * 16 * EP;
+    float* xf_tab = reinterpret_cast<float*>(ring + NS * STAGE + NW * 16 * EP);  // XF: [2][C] scale, shift
+    if constexpr (XF) {
+        for (int i = tid; i < 2 * p.C; i += NW * 64) xf_tab[i] = p.xf[2 * p.C + i];
+        __syncthreads();
+    }
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int total_tiles = tiles_m * tiles_n;
@@ -766,6 +782,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 // NS - 1 stages are always in flight here (the loader never stops issuing)
                 wait_vm_and_barrier<(NS - 2) * LPW>();
                 plain_issue();
+                if constexpr (XF) {
+                    bf16* sAx = ring + slot * STAGE;
+                    const int cbase = s * BK;
+#pragma unroll
+                    for (int i = 0; i < (BM * 8) / (NW * 64); ++i) {
+                        const int q = tid + i * (NW * 64);
+                        const int row = q >> 3, pos = q & 7;
+                        const int cb = cbase + ((pos ^ (row & 7)) << 3);  // channels of this physical chunk
+                        bf16* a = sAx + row * BK + (pos << 3);
+                        bf16x8 v = *reinterpret_cast<const bf16x8*>(a);
+                        float sc[8], sh[8];
+                        *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(xf_tab + cb);
+                        *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(xf_tab + cb + 4);
+                        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(xf_tab + p.C + cb);
+                        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(xf_tab + p.C + cb + 4);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * sc[e] + sh[e], 0.f));
+                        *reinterpret_cast<bf16x8*>(a) = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
                 compute(slot);
                 plain_advance();
             } else {
@@ -970,7 +1007,7 @@ static int pdt_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP, bool XF = false>
 static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream);
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PP = false>
@@ -981,15 +1018,18 @@ static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stre
     return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, EPI, BK, false, PP>(a, stream);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP, bool XF>
 static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream) {
     if ((a.C % BK) != 0) return -1;
-    constexpr size_t lds = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
-    static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
-    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK, PLAIN, PP>;
+    constexpr size_t lds_base = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
+    static_assert(lds_base <= 160 * 1024, "ring does not fit the LDS of a CU");
+    const size_t lds = lds_base + (XF ? static_cast<size_t>(a.C) * 2 * sizeof(float) : 0);  // + the scale / shift table
+    if (lds > 160 * 1024) return -1;
+    auto kernel = gather_gemm_ring_kernel<BM, BN, WM, WN, NS, EPI, BK, PLAIN, PP, XF>;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(XF ? 160 * 1024 : lds_base));
         if (e != hipSuccess) return static_cast<int>(e);
         configured = true;
     }
@@ -1004,6 +1044,16 @@ static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t st
 template <int BM, int BN, int WM, int WN, int NS, int BK = GG_BK, bool PP = false>
 static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) {
     if (a.zeros == nullptr) return -1;
+    if (a.xf != nullptr) {
+        // operand transform: plain epilogue (+ statistics), single tap in bounds, two-stage tile, not ping-pong
+        const bool plain = a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && (a.OA - 1) * a.istr < a.Hin && (a.OB - 1) * a.istr < a.Win;
+        if constexpr (NS == 2 && !PP && BK == 64) {
+            if (!plain || a.act != 0 || a.bn_y != nullptr || a.bias != nullptr || a.addend != nullptr) return -1;
+            return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 0, BK, true, false, true>(a, stream);
+        } else {
+            return -1;
+        }
+    }
     if (a.act != 0) {
         if (a.bn_y != nullptr || a.addend != nullptr || a.stats != nullptr) return -1;
         if (a.act == 1 && a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 33, BK, PP>(a, stream);
@@ -1042,7 +1092,8 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
                             const int* tap_woff, int tile, int smallc, const void* zeros, const void* bn_y,
                             const float* bn_consts, const void* bn_bits, const void* bn_y2, const float* bn_consts2,
-                            int act, void* out2, const void* act_src, void* stream) {
+                            int act, void* out2, const void* act_src, const float* xf, void* stream) {
+    if (xf != nullptr && (smallc || tile != 16)) return -1;  // the operand transform lives in the 256x256 two-stage kernel
     if (act < 0 || act > 2 || (act == 1 && (out2 == nullptr || bias == nullptr)) || (act == 2 && act_src == nullptr)) return -1;
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
@@ -1066,6 +1117,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.bn_consts2 = bn_consts2;
     if (bn_y2 != nullptr && bn_y == nullptr) return -1;
     a.stat_rows = bn_y != nullptr ? 3 : 2;
+    a.xf = xf;
     a.act = act;
     a.out_nt = g_out_nt_bytes < 0 ? 2 : (static_cast<long long>(M) * N * 2 >= g_out_nt_bytes);
     a.out2 = static_cast<bf16*>(out2);
@@ -1133,6 +1185,7 @@ struct WgradArgs {
     float* dW;
     const bf16* zeros;  // >= 16 bytes of zeros (ring variant)
     float* dbias;       // ring variant: column sums of dY (the bias gradient) are added here, or nullptr
+    const float* xf;    // ring variant, single tap: the X operand is relu(X * scale[c] + shift[c]); [4][C] BatchNorm constants
     int M, N, ldy, C, T, ldw;
     int Hin, Win, istr, OA, OB;
     FastDiv div_ab, div_b, div_c;
@@ -1322,8 +1375,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // advance by 64 rows per stage, and the loader issues unconditionally (rows beyond the split's range come
 // from the zero page), which leaves one basic block per K-step (see gather_gemm_ring_kernel).
 // `block` is the workgroup's index inside its problem's grid of gx x (nblocks / gx) workgroups.
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
+// XF (PLAIN only): the X operand is the BatchNorm + ReLU of the stored tensor, recomputed on the way in: every X stage
+// is transformed in place in LDS after it has landed (a thread rewrites its 16-byte chunks with the scale / shift of
+// their channels from a table in LDS), then a second barrier.  Rows beyond the pixel range hold relu(shift) instead of
+// zero after that, which is harmless: the dY rows they are multiplied with are zero.
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF = false>
 __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, int gx, int nblocks) {
+    static_assert(!XF || (PLAIN && MODE == 0), "operand transform: single-tap launches");
     constexpr int KM = 64;                       // pixels per K-step
     constexpr int NW = WN * WC;
     constexpr int TN = BN / WN, TC = BC / WC;    // per-wave tile
@@ -1352,6 +1410,14 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     const int ms = split * p.m_per_split;
     const int me = min(p.M, ms + p.m_per_split);
     const int nsteps = (me - ms + KM - 1) / KM;
+    float* xf_tab = reinterpret_cast<float*>(ring + NS * STAGE);  // XF: [2][BC] scale, shift of channels c0 .. c0 + BC
+    if constexpr (XF) {
+        for (int i = tid; i < 2 * BC; i += NW * 64) {
+            const int which = i / BC, c = c0 + (i - which * BC);
+            xf_tab[i] = c < p.C ? p.xf[(2 + which) * p.C + c] : 0.f;
+        }
+        __syncthreads();
+    }
 
     // 32-byte units of a row are XOR-ed with a function of the row so that the 8 consecutive rows one half of a
     // transposed read touches fall on 8 distinct bank groups: row & 7 for rows of 256 bytes or more (every row
@@ -1540,6 +1606,27 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
         if constexpr (PLAIN) {
             wait_vm_and_barrier<(NS - 2) * LPW>();  // NS - 1 stages are always in flight here
             plain_issue();
+            if constexpr (XF) {
+                bf16* sXx = ring + slot * STAGE + KM * BN;
+#pragma unroll
+                for (int i = 0; i < (KM * XCH + NW * 64 - 1) / (NW * 64); ++i) {
+                    const int q = tid + i * (NW * 64);
+                    if ((KM * XCH) % (NW * 64) != 0 && q >= KM * XCH) break;
+                    const int row = q / XCH, pc = q % XCH;
+                    const int cb = ((((pc >> 1) ^ swz_x(row)) << 1) | (pc & 1)) << 3;  // channels (relative to c0) of this chunk
+                    bf16* a = sXx + row * BC + (pc << 3);
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(a);
+                    float sc[8], sh[8];
+                    *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(xf_tab + cb);
+                    *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(xf_tab + cb + 4);
+                    *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(xf_tab + BC + cb);
+                    *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(xf_tab + BC + cb + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * sc[e] + sh[e], 0.f));
+                    *reinterpret_cast<bf16x8*>(a) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         } else {
             if (ld_issued - (s + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
             else wait_vm_and_barrier<0>();
@@ -1585,9 +1672,9 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     }
 }
 
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false>
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false, bool XF = false>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
-    wgrad_ring_body<BN, BC, WN, WC, NS, MODE, PLAIN>(p, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.x * gridDim.y);
+    wgrad_ring_body<BN, BC, WN, WC, NS, MODE, PLAIN, XF>(p, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.x * gridDim.y);
 }
 
 // Two independent weight-gradient problems of the same tile shape in one launch (workgroups [0, n0) belong to the
@@ -1602,25 +1689,28 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_dual_kernel(const Wgr
     else wgrad_ring_body<BN, BC, WN, WC, NS, 0, true>(p1, b - n0, gx1, n1);
 }
 
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF = false>
 static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream);
 
 template <int BN, int BC, int WN, int WC, int NS, int MODE = 0>
 static int launch_wgrad_ring(const WgradArgs& a, int gy, hipStream_t stream) {
     if constexpr (MODE == 0) {
         // output pixel m reads input pixel m: the pointer-walking loader applies
-        if (a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && a.istr == 1 && a.OA == a.Hin && a.OB == a.Win)
+        if (a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && a.istr == 1 && a.OA == a.Hin && a.OB == a.Win) {
+            if (a.xf != nullptr) return launch_wgrad_ring_plain<BN, BC, WN, WC, NS, MODE, true, true>(a, gy, stream);
             return launch_wgrad_ring_plain<BN, BC, WN, WC, NS, MODE, true>(a, gy, stream);
+        }
     }
+    if (a.xf != nullptr) return -1;  // the operand transform needs the single-tap form
     return launch_wgrad_ring_plain<BN, BC, WN, WC, NS, MODE, false>(a, gy, stream);
 }
 
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN>
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF>
 static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream) {
-    constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16);
+    constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16) + (XF ? 2 * BC * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
     if (a.zeros == nullptr) return -1;
-    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE, PLAIN>;
+    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE, PLAIN, XF>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -1698,7 +1788,7 @@ PDT_API int pdt_wgrad_group_end(void* stream) {
 // dW must be zero (or hold a value to accumulate onto) before the call.
 PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
                       int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
-                      int splits, int tile, int smallc, const void* zeros, float* dbias, void* stream) {
+                      int splits, int tile, int smallc, const void* zeros, float* dbias, const float* xf, void* stream) {
     // rows of dY are read in 8-column chunks: ldy must cover N rounded up to 8 (columns >= N are ignored)
     if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8) return -1;
     if (!smallc && (C % 8) != 0) return -1;
@@ -1709,6 +1799,8 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.dW = dW;
     a.zeros = static_cast<const bf16*>(zeros);
     a.dbias = dbias;
+    a.xf = xf;
+    if (xf != nullptr && (tile < 10 || tile == 15 || smallc || wgrad_grouping)) return -1;  // ring kernels, single launches
     if (dbias != nullptr && (tile < 10 || tile == 15)) return -1;  // only the MODE 0 ring kernels sum the bias gradient
     a.M = M; a.N = N; a.ldy = ldy; a.C = C; a.T = T; a.ldw = ldw;
     a.Hin = Hin; a.Win = Win; a.istr = istr; a.OA = OA; a.OB = OB;

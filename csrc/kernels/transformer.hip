@@ -413,3 +413,134 @@ PDT_API int pdt_embedding_bwd(const long long* ids, const void* g, float* dw, lo
                        static_cast<const bf16*>(g), dw, n, D, vocab);
     return pdt_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Token + position embedding in one pass (language models):  out[b][t] = bf16(W[ids[b][t]] + P[t]).
+// Gradient of the position table: dP[t] += sum_b g[b][t] - one thread owns 8 channels of one position and walks
+// the batch, so no atomics and no [B, S, D] -> [S, D] reduction pass; the token table uses embedding_bwd.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_pos_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ w,
+                                                               const float* __restrict__ pos, bf16* __restrict__ out, long long n,
+                                                               int D, long long vocab, int S) {
+    const int dvec = D >> 3;
+    const long long nvec = n * dvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const long long i = v / dvec;
+        const int c = static_cast<int>(v - i * dvec) << 3;
+        long long id = ids[i];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const int t = static_cast<int>(i % S);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + id * D + c), b = *reinterpret_cast<const f32x4*>(w + id * D + c + 4);
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(pos + static_cast<long long>(t) * D + c),
+                    pb = *reinterpret_cast<const f32x4*>(pos + static_cast<long long>(t) * D + c + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = f32_to_bf16(a[e] + pa[e]);
+            o[e + 4] = f32_to_bf16(b[e] + pb[e]);
+        }
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+    }
+}
+
+// dst[r][c] += sum over b of g[b][row0 + r][c]  for r in [0, R): g is [B][S][D] bf16, dst is [R][D] fp32
+__global__ __launch_bounds__(256) void batch_rowsum_kernel(const bf16* __restrict__ g, float* __restrict__ dst, int B, int S, int D,
+                                                          int row0, int R) {
+    const int dvec = D >> 3;
+    const long long nvec = static_cast<long long>(R) * dvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const int r = static_cast<int>(v / dvec);
+        const int c = static_cast<int>(v - static_cast<long long>(r) * dvec) << 3;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const bf16* src = g + (static_cast<long long>(row0 + r)) * D + c;
+        for (int b = 0; b < B; ++b) {
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(src + static_cast<long long>(b) * S * D);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32(gv[e]);
+        }
+        float* d = dst + static_cast<long long>(r) * D + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] += acc[e];
+    }
+}
+
+PDT_API int pdt_embedding_pos_fwd(const long long* ids, const float* w, const float* pos, void* out, long long n, int D,
+                                  long long vocab, int S, void* stream) {
+    if (n <= 0 || D <= 0 || (D % 8) != 0 || vocab <= 0 || S <= 0) return -1;
+    hipLaunchKernelGGL(embedding_pos_fwd_kernel, dim3(ew_grid8(n * (D / 8))), dim3(256), 0, static_cast<hipStream_t>(stream), ids, w,
+                       pos, static_cast<bf16*>(out), n, D, vocab, S);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_batch_rowsum(const void* g, float* dst, int B, int S, int D, int row0, int R, void* stream) {
+    if (B <= 0 || S <= 0 || D <= 0 || (D % 8) != 0 || row0 < 0 || R <= 0 || row0 + R > S) return -1;
+    hipLaunchKernelGGL(batch_rowsum_kernel, dim3(ew_grid8(static_cast<long long>(R) * (D / 8))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(g), dst, B, S, D, row0, R);
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vision-transformer token assembly:  h[b][0] = cls + P[0],  h[b][1 + t] = tok[b][t] + P[1 + t]
+// (class token and position table are fp32 parameters, tok the bf16 patch embedding), and the part of its gradient
+// that is a copy: dtok[b][t] = g[b][1 + t].  The parameter gradients come from batch_rowsum_kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const bf16* __restrict__ tok, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, bf16* __restrict__ out, int B, int T,
+                                                              int D) {
+    const int dvec = D >> 3;
+    const long long nvec = static_cast<long long>(B) * (T + 1) * dvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const long long row = v / dvec;
+        const int c = static_cast<int>(v - row * dvec) << 3;
+        const int b = static_cast<int>(row / (T + 1)), t = static_cast<int>(row - static_cast<long long>(b) * (T + 1));
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(pos + static_cast<long long>(t) * D + c),
+                    pb = *reinterpret_cast<const f32x4*>(pos + static_cast<long long>(t) * D + c + 4);
+        float x[8];
+        if (t == 0) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(cls + c), bb = *reinterpret_cast<const f32x4*>(cls + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = a[e];
+                x[e + 4] = bb[e];
+            }
+        } else {
+            const bf16x8 tv = *reinterpret_cast<const bf16x8*>(tok + (static_cast<long long>(b) * T + (t - 1)) * D + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = bf16_to_f32(tv[e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = f32_to_bf16(x[e] + pa[e]);
+            o[e + 4] = f32_to_bf16(x[e + 4] + pb[e]);
+        }
+        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const bf16* __restrict__ g, bf16* __restrict__ dtok, int B, int T, int D) {
+    const int dvec = D >> 3;
+    const long long nvec = static_cast<long long>(B) * T * dvec;
+    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
+        const long long row = v / dvec;
+        const int c = static_cast<int>(v - row * dvec) << 3;
+        const long long b = row / T, t = row - b * T;
+        *reinterpret_cast<bf16x8*>(dtok + v * 8) = *reinterpret_cast<const bf16x8*>(g + (b * (T + 1) + t + 1) * D + c);
+    }
+}
+
+PDT_API int pdt_vit_assemble_fwd(const void* tok, const float* cls, const float* pos, void* out, int B, int T, int D, void* stream) {
+    if (B <= 0 || T <= 0 || D <= 0 || (D % 8) != 0) return -1;
+    hipLaunchKernelGGL(vit_assemble_fwd_kernel, dim3(ew_grid8(static_cast<long long>(B) * (T + 1) * (D / 8))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(tok), cls, pos, static_cast<bf16*>(out), B, T, D);
+    return pdt_launch_status();
+}
+
+PDT_API int pdt_vit_assemble_bwd(const void* g, void* dtok, int B, int T, int D, void* stream) {
+    if (B <= 0 || T <= 0 || D <= 0 || (D % 8) != 0) return -1;
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(ew_grid8(static_cast<long long>(B) * T * (D / 8))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(g), static_cast<bf16*>(dtok), B, T, D);
+    return pdt_launch_status();
+}

@@ -48,8 +48,7 @@ class GPT2(nn.Module):
         b, s = idx.shape
         if s > self.n_ctx:
             raise ValueError(f"sequence length {s} exceeds context {self.n_ctx}")
-        pos = torch.arange(s, device=idx.device)
-        x = ops.embedding(idx, self.wte.weight) + ops.embedding(pos, self.wpe.weight).unsqueeze(0)
+        x = ops.token_position_embedding(idx, self.wte.weight, self.wpe.weight)
         for blk in self.h:
             x = blk(x)
         x = ops.layer_norm(x, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)

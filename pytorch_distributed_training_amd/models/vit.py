@@ -90,9 +90,7 @@ class VisionTransformer(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         tok = ops.linear(self._patches(x), self.patch_embed.weight, self.patch_embed.bias)
-        b = tok.shape[0]
-        cls = self.class_token.to(tok.dtype).expand(b, -1, -1)
-        h = torch.cat([cls, tok], dim=1) + self.pos_embedding.to(tok.dtype)
+        h = ops.vit_assemble(tok, self.class_token, self.pos_embedding)
         for blk in self.layers:
             h = blk(h)
         h = ops.layer_norm(h, self.ln.weight, self.ln.bias, self.ln.eps)

@@ -154,6 +154,24 @@ def embedding(ids, weight):
     return _ref.embedding(ids, weight)
 
 
+def token_position_embedding(ids, wte, wpe):
+    """Input embedding of a language model: ``wte[ids] + wpe[position]`` for ``ids`` of shape ``[B, S]``."""
+    if wte.is_cuda:
+        from . import hip_transformer as ht
+
+        return ht.token_position_embedding(ids, wte, wpe)
+    return _ref.token_position_embedding(ids, wte, wpe)
+
+
+def vit_assemble(tok, cls, pos):
+    """Vision-transformer token sequence: class token in front of the patch tokens, plus the position table."""
+    if tok.is_cuda:
+        from . import hip_transformer as ht
+
+        return ht.vit_assemble(tok, cls, pos)
+    return _ref.vit_assemble(tok, cls, pos)
+
+
 def add_bias_residual(x, bias, residual):
     if x.is_cuda:
         return _hip().add_bias_residual(x, bias, residual)

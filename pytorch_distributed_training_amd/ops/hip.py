@@ -41,9 +41,9 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
-_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp])
+_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp, _vp])
 _lib.pdt_wgrad_group_begin.argtypes = []
 _lib.pdt_wgrad_group_begin.restype = None
 _wgrad_group_end = _sig("pdt_wgrad_group_end", [_vp])
@@ -499,11 +499,13 @@ def _pick_tile(m: int, n: int, ksteps: int = 1) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None, gelu_out=None, gelu_of=None) -> None:
+                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None, gelu_out=None, gelu_of=None, xf=None) -> None:
     """``bn_stat = (y, consts, bits_or_None[, y2, consts2])``: also accumulate BatchNorm-backward sums of the result into ``stats``
     ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`).
     ``gelu_out``: tensor (layout of ``out``) that receives gelu(result) while ``out`` keeps the pre-activation.
-    ``gelu_of``: pre-activation tensor (layout of ``out``); the result is multiplied by gelu'(gelu_of)."""
+    ``gelu_of``: pre-activation tensor (layout of ``out``); the result is multiplied by gelu'(gelu_of).
+    ``xf``: [4, C] BatchNorm constants; the A operand is relu(a * scale + shift) per input channel, applied in the
+    kernel (single-tap launches on the 256x256 tile only, see :func:`_can_fuse_bn_into_conv`)."""
     bn_y = bn_consts = bn_bits = bn_y2 = bn_consts2 = None
     if bn_stat is not None:
         bn_y, bn_consts, bn_bits = bn_stat[:3]
@@ -513,7 +515,7 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
     tile = _pick_tile(M, N, len(taps) * max(C // 64, 1))
     if _TILE_FUSED_TAIL >= 0 and bn_bits is not None and tile == 16:
         tile = _TILE_FUSED_TAIL
-    if tile == 16 and _GEMM_PP and (_GEMM_PP > 1 or (len(taps) == 1 and C >= 512)):
+    if tile == 16 and xf is None and _GEMM_PP and (_GEMM_PP > 1 or (len(taps) == 1 and C >= 512)):
         tile = 17
     _check(
         _gather_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(stats), _ptr(bias), _ptr(addend), _ptr(addend_bits), M, N,
@@ -521,7 +523,8 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
                      Hin, Win, istr, OA, OB, Hout, Wout, ostr, oph, opw, dh, dw, wo,
                      tile, int(smallc),
                      _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _ptr(bn_y2), _ptr(bn_consts2),
-                     1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _stream()),
+                     1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _ptr(xf),
+                     _stream()),
         "gather_gemm",
     )
 
@@ -583,7 +586,7 @@ def _wgrad_ring_choice(M: int, N: int, kc: int) -> int:
     return best
 
 
-def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=0, dbias=None) -> bool:
+def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, smallc=0, dbias=None, xf=None) -> bool:
     """Launch the weight-gradient kernel.  ``dbias``: fp32 [N] buffer that should also receive the column sums
     of ``dy`` (the bias gradient); returns True when the chosen kernel did that, False when the caller still
     has to (only the ring kernels can)."""
@@ -611,7 +614,8 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
     fuse_bias = dbias is not None and tile >= 10 and tile != 15
     _check(
         _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
-               wo, splits, tile, int(smallc), _zero_page(dy.device).data_ptr(), _ptr(dbias) if fuse_bias else None, _stream()),
+               wo, splits, tile, int(smallc), _zero_page(dy.device).data_ptr(), _ptr(dbias) if fuse_bias else None, _ptr(xf),
+               _stream()),
         "wgrad",
     )
     return fuse_bias
@@ -668,7 +672,9 @@ def _packed_rows_weight(weight: torch.Tensor, cp: int, tw: int, kpad: int) -> to
         return hit[2]
     n, c, r, s = weight.shape
     w = weight.detach().permute(0, 2, 3, 1)  # [n][r][s][c]
-    buf = torch.zeros((n, kpad), dtype=torch.bfloat16, device=weight.device)
+    # the buffer of the previous step is reused: its padding positions are zero already, only the live entries change
+    buf = hit[2] if (hit is not None and hit[0]() is weight and hit[2].shape == (n, kpad) and hit[1][3:] == (cp, tw, kpad)) \
+        else torch.zeros((n, kpad), dtype=torch.bfloat16, device=weight.device)
     buf[:, : r * tw].view(n, r, tw // cp, cp)[:, :, :s, :c].copy_(w)
     import weakref
 
@@ -1031,7 +1037,82 @@ def bn_act(y, stats, bn, relu: bool = True):
     return _BnAct.apply(y, stats, bn.weight, bn.bias, bn, relu, None)
 
 
+FUSE_BN_INTO_1X1 = int(_os.environ.get("PDT_FUSE_BN_1X1", "1"))
+
+
+def _can_fuse_bn_into_conv(y_prev, bn, weight, stride: int, padding: int) -> bool:
+    """BatchNorm + ReLU can be applied inside the consuming convolution's kernels (forward GEMM and weight gradient)
+    when that convolution is 1x1 / stride 1 (no padding pixels, one tap), training-mode statistics are in use and the
+    shapes land on the kernels that carry the transform: the 256x256 two-stage GEMM tile and a ring weight-gradient
+    kernel."""
+    if not FUSE_BN_INTO_1X1 or not WGRAD_RING or WGRAD_RING >= 10 or _TILE_WIDE >= 0:
+        return False
+    n, c, r, s = weight.shape
+    if (r, s) != (1, 1) or stride != 1 or padding != 0 or not bn.training or c % 64 or n % 64 or c > 2048:
+        return False
+    nb, _, h, w = y_prev.shape
+    M = nb * h * w
+    if _pick_tile(M, n, c // 64) != 16:
+        return False
+    return (n >= 128 and c >= 128) or (n >= 256 and c < 128)  # the weight-gradient launch is a ring kernel
+
+
+class _BnReluConv1x1(torch.autograd.Function):
+    """conv1x1(relu(bn(y_prev))) without ever writing relu(bn(y_prev)): the forward GEMM and the weight-gradient
+    kernel normalise their operand tiles in LDS, the data-gradient kernel takes BatchNorm's backward sums in its
+    epilogue (mask recomputed from y_prev), and BatchNorm's backward apply pass produces the gradient of y_prev."""
+
+    @staticmethod
+    def forward(ctx, y_prev, stats_prev, gamma, beta, bn, weight):
+        y_prev = _as_nhwc(y_prev)
+        nb, c, h, w_ = y_prev.shape
+        n = weight.shape[0]
+        count = M = nb * h * w_
+        consts = _bn_consts(stats_prev, bn, count, y_prev.device)
+        y = _empty_nhwc(nb, n, h, w_, y_prev.device)
+        _check_size(y)
+        stats = ARENA.alloc((STAT_SLOTS, 2, n), y_prev.device)
+        one = [(0, 0, 0)]
+        _launch_gather_gemm(y_prev, SHADOWS.fwd(weight), y, stats, None, M, n, c, n, c, one, h, w_, 1, h, w_, h, w_, 1, 0, 0,
+                            xf=consts)
+        ctx.save_for_backward(y_prev, consts, weight, gamma, beta)
+        ctx.geom = (nb, c, h, w_, n)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        y_prev, consts, weight, gamma, beta = ctx.saved_tensors
+        nb, c, h, w_, n = ctx.geom
+        if dy is None:
+            return None, None, None, None, None, None
+        dy = _as_nhwc(dy)
+        count = M = nb * h * w_
+        one = [(0, 0, 0)]
+        dw = None
+        if ctx.needs_input_grad[5]:
+            sink = _grad_sink(weight, (n, 1, 1, c))
+            dwp = sink if sink is not None else torch.zeros((n, 1, 1, c), dtype=torch.float32, device=dy.device)
+            _launch_wgrad(dy, y_prev, dwp, M, n, n, c, one, c, h, w_, 1, h, w_, xf=consts)
+            if sink is None:
+                dw = dwp.permute(0, 3, 1, 2)
+        dyp = dgamma = dbeta = None
+        if ctx.needs_input_grad[0]:
+            wt, npad = SHADOWS.dgrad(weight, 1)
+            da = _empty_nhwc(nb, c, h, w_, dy.device)
+            slots = bn_stat = None
+            if _dgrad_can_fuse_stats([(M, c)]):
+                slots = ARENA.alloc((STAT_SLOTS, 3, c), dy.device)
+                bn_stat = (y_prev, consts, None)
+            _launch_gather_gemm(dy, wt, da, slots, None, M, c, npad, c, n, one, h, w_, 1, h, w_, h, w_, 1, 0, 0, bn_stat=bn_stat)
+            dyp, dgamma, dbeta, _ = _bn_backward(da, None, y_prev, consts, gamma, beta, count, c, mask_mode=2, slots=slots)
+        return dyp, None, dgamma, dbeta, None, dw
+
+
 def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
+    if _can_fuse_bn_into_conv(y_prev, bn, weight, stride, padding):
+        return _BnReluConv1x1.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, weight)
     sl = StatLink()  # the convolution's data-gradient kernel also reduces for BatchNorm's backward
     a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True, sl)
     return _ConvStats.apply(a, weight, stride, padding, bn.training, None, None, sl)
@@ -1282,8 +1363,8 @@ def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None
     out = _Linear.apply(x, weight, bias, residual, link)
     if activation == "gelu":
         return gelu(out)
-    if activation == "relu":
-        return torch.relu(out)
+    if activation is not None:
+        raise ValueError("activation must be None or 'gelu'")
     return out
 
 

@@ -33,6 +33,10 @@ _gelu_bwd = _sig("pdt_gelu_bwd", [_vp, _vp, _vp, _ll, _vp])
 _bias_res = _sig("pdt_bias_residual", [_vp, _vp, _vp, _vp, _ll, _i, _vp])
 _emb_fwd = _sig("pdt_embedding_fwd", [_vp, _vp, _vp, _ll, _i, _ll, _vp])
 _emb_bwd = _sig("pdt_embedding_bwd", [_vp, _vp, _vp, _ll, _i, _ll, _vp])
+_emb_pos_fwd = _sig("pdt_embedding_pos_fwd", [_vp, _vp, _vp, _vp, _ll, _i, _ll, _i, _vp])
+_batch_rowsum = _sig("pdt_batch_rowsum", [_vp, _vp, _i, _i, _i, _i, _i, _vp])
+_vit_asm_fwd = _sig("pdt_vit_assemble_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp])
+_vit_asm_bwd = _sig("pdt_vit_assemble_bwd", [_vp, _vp, _i, _i, _i, _vp])
 _attn_fwd = _sig("pdt_attention_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp])
 _attn_bwd = _sig("pdt_attention_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp])
 
@@ -190,6 +194,95 @@ class _Embedding(torch.autograd.Function):
 
 def embedding(ids, weight):
     return _Embedding.apply(ids, weight)
+
+
+def _param_grad_target(param, shape, device):
+    """(buffer to accumulate a parameter's fp32 gradient into, whether it is the parameter's own ``.grad``)."""
+    sink = _grad_sink(param, shape)
+    if sink is not None:
+        return sink, True
+    return torch.zeros(shape, dtype=torch.float32, device=device), False
+
+
+class _TokenPositionEmbedding(torch.autograd.Function):
+    """``wte[ids] + wpe[position]`` -> bf16 ``[B, S, D]`` in one kernel; the position table's gradient is a sum over
+    the batch taken by a kernel that owns each (position, channel) - no broadcast add, no reduction pass."""
+
+    @staticmethod
+    def forward(ctx, ids, wte, wpe):
+        b, s = ids.shape
+        ids_c = ids.reshape(-1).to(torch.int64).contiguous()
+        vocab, d = wte.shape
+        if wpe.shape[0] < s or wpe.shape[1] != d or not wte.is_contiguous() or not wpe.is_contiguous():
+            raise ValueError("position table too short or of a different width")
+        out = torch.empty((b, s, d), dtype=torch.bfloat16, device=wte.device)
+        _check(_emb_pos_fwd(ids_c.data_ptr(), wte.data_ptr(), wpe.data_ptr(), out.data_ptr(), ids_c.numel(), d, vocab, s,
+                            _stream()), "embedding_pos_fwd")
+        ctx.save_for_backward(ids_c)
+        ctx.tables = (wte, wpe)
+        ctx.meta = (b, s, d, vocab)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids_c,) = ctx.saved_tensors
+        wte, wpe = ctx.tables
+        b, s, d, vocab = ctx.meta
+        g2 = _bf16c(g).reshape(b, s, d)
+        dwte = dwpe = None
+        if ctx.needs_input_grad[1]:
+            buf, own = _param_grad_target(wte, (vocab, d), g.device)
+            _check(_emb_bwd(ids_c.data_ptr(), g2.data_ptr(), buf.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_bwd")
+            dwte = None if own else buf
+        if ctx.needs_input_grad[2]:
+            buf, own = _param_grad_target(wpe, tuple(wpe.shape), g.device)
+            _check(_batch_rowsum(g2.data_ptr(), buf.data_ptr(), b, s, d, 0, s, _stream()), "batch_rowsum")
+            dwpe = None if own else buf
+        return None, dwte, dwpe
+
+
+def token_position_embedding(ids, wte, wpe):
+    return _TokenPositionEmbedding.apply(ids, wte, wpe)
+
+
+class _VitAssemble(torch.autograd.Function):
+    """``cat([cls, tok], 1) + pos`` -> bf16 ``[B, T + 1, D]`` in one kernel (class token and position table are fp32
+    parameters); backward: one copy kernel for the patch tokens' gradient, batch sums for the two parameters."""
+
+    @staticmethod
+    def forward(ctx, tok, cls, pos):
+        tok = _bf16c(tok)
+        b, t, d = tok.shape
+        if cls.numel() != d or pos.numel() != (t + 1) * d or not cls.is_contiguous() or not pos.is_contiguous():
+            raise ValueError("class token / position table do not match the token grid")
+        out = torch.empty((b, t + 1, d), dtype=torch.bfloat16, device=tok.device)
+        _check(_vit_asm_fwd(tok.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), b, t, d, _stream()), "vit_assemble_fwd")
+        ctx.params = (cls, pos)
+        ctx.meta = (b, t, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cls, pos = ctx.params
+        b, t, d = ctx.meta
+        g2 = _bf16c(g).reshape(b, t + 1, d)
+        dtok = dcls = dpos = None
+        if ctx.needs_input_grad[0]:
+            dtok = torch.empty((b, t, d), dtype=torch.bfloat16, device=g.device)
+            _check(_vit_asm_bwd(g2.data_ptr(), dtok.data_ptr(), b, t, d, _stream()), "vit_assemble_bwd")
+        if ctx.needs_input_grad[1]:
+            buf, own = _param_grad_target(cls, tuple(cls.shape), g.device)
+            _check(_batch_rowsum(g2.data_ptr(), buf.data_ptr(), b, t + 1, d, 0, 1, _stream()), "batch_rowsum")
+            dcls = None if own else buf
+        if ctx.needs_input_grad[2]:
+            buf, own = _param_grad_target(pos, tuple(pos.shape), g.device)
+            _check(_batch_rowsum(g2.data_ptr(), buf.data_ptr(), b, t + 1, d, 0, t + 1, _stream()), "batch_rowsum")
+            dpos = None if own else buf
+        return dtok, dcls, dpos
+
+
+def vit_assemble(tok, cls, pos):
+    return _VitAssemble.apply(tok, cls, pos)
 
 
 class _AttentionQKV(torch.autograd.Function):

@@ -66,8 +66,8 @@ def linear(x, weight, bias=None, activation: Optional[str] = None, residual=None
         out = out + residual
     if activation == "gelu":
         out = F.gelu(out, approximate="tanh")
-    elif activation == "relu":
-        out = F.relu(out)
+    elif activation is not None:
+        raise ValueError("activation must be None or 'gelu'")
     return out
 
 
@@ -110,6 +110,18 @@ def attention_qkv(qkv, heads: int, causal: bool = False):
 
 def embedding(ids, weight):
     return F.embedding(ids, weight)
+
+
+def token_position_embedding(ids, wte, wpe):
+    """``wte[ids] + wpe[0..S)`` for ``ids`` of shape ``[B, S]``."""
+    s_ = ids.shape[1]
+    return F.embedding(ids, wte) + wpe[:s_].unsqueeze(0)
+
+
+def vit_assemble(tok, cls, pos):
+    """``cat([cls, tok], dim=1) + pos``: class token in front of the patch tokens, position table added."""
+    b = tok.shape[0]
+    return torch.cat([cls.to(tok.dtype).expand(b, -1, -1), tok], dim=1) + pos.to(tok.dtype)
 
 
 def add_bias_residual(x, bias, residual):

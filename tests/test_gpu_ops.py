@@ -712,3 +712,57 @@ def test_u8_image_batch_to_bf16_nhwc(shape):
         assert out.shape == (n, 3, h, w) and out.is_contiguous(memory_format=torch.channels_last) or n * h * w < 8
         ref = ops.image_batch_to_device_layout(x, torch.float32, m, s)
         assert torch.equal(out.float().cpu(), ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("case", [(16, 64, 256, 56, True), (64, 128, 512, 28, True), (128, 512, 2048, 7, True),
+                                  (53, 256, 1024, 14, True),  # 10 388 rows: the last 256-row tile is partial
+                                  (8, 256, 1024, 14, False)])  # too few tiles for the kernel that carries the transform
+def test_bn_relu_fused_into_the_1x1_convolution_kernels(hip, monkeypatch, case):
+    """conv1x1(relu(bn(y))) with the normalisation applied inside the forward GEMM and the weight-gradient kernel
+    (the normalised activation is never written): output, statistics and all four gradients against the path that
+    materialises relu(bn(y)), and against fp32 PyTorch on the same operands."""
+    torch.manual_seed(5)
+    dev = _dev()
+    nb, cin, cout, hw, fusable = case
+    y = hip.to_device_layout(torch.randn(nb, cin, hw, hw, device=dev) * 1.5 + 0.2)
+    w = nn.Parameter((torch.randn(cout, cin, 1, 1, device=dev) / math.sqrt(cin)).contiguous(memory_format=torch.channels_last))
+    gamma, beta = torch.empty(cin, device=dev).uniform_(0.5, 1.5), torch.empty(cin, device=dev).uniform_(-0.5, 0.5)
+    yf = y.float()
+    st = torch.zeros(hip.STAT_SLOTS, 2, cin, device=dev)
+    st[0, 0] = yf.sum(dim=(0, 2, 3))
+    st[0, 1] = (yf * yf).sum(dim=(0, 2, 3))
+    g = torch.randn(nb, cout, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    launched = []
+    real_launch = hip._launch_gather_gemm
+    monkeypatch.setattr(hip, "_launch_gather_gemm", lambda *a, **kw: (launched.append(kw.get("xf") is not None), real_launch(*a, **kw))[1])
+    for fused in (True, False):
+        monkeypatch.setattr(hip, "FUSE_BN_INTO_1X1", 1 if fused else 0)
+        bn = nn.BatchNorm2d(cin).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(gamma)
+            bn.bias.copy_(beta)
+        for p in list(bn.parameters()) + [w]:
+            p.grad = None
+        yy = y.clone().requires_grad_(True)
+        launched.clear()
+        out, stats = hip.bn_relu_conv2d(yy, st.clone(), bn, w, 1, 0)
+        assert any(launched) == (fused and fusable), "the operand transform was (not) used"
+        out.backward(g)
+        torch.cuda.synchronize()
+        res[fused] = (out.float().clone(), stats.sum(0).clone(), yy.grad.float().clone(), bn.weight.grad.clone(),
+                      bn.bias.grad.clone(), w.grad.clone(), bn.running_mean.clone())
+    for name, a, b in zip(("out", "stats", "dy", "dgamma", "dbeta", "dw", "running_mean"), res[True], res[False]):
+        assert _rel_err(a, b) < 4e-3, name
+    # fp32 reference: batch statistics, affine, relu, 1x1 convolution on the bf16-rounded operands
+    yr = yf.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    wr = _bf16_round(w.detach()).requires_grad_(True)
+    a = F.relu(F.batch_norm(yr, None, None, gr, br, training=True, eps=1e-5))
+    o = F.conv2d(a, wr)
+    o.backward(g.float())
+    out, _, dy, dgamma, dbeta, dw, _ = res[True]
+    assert _rel_err(out, o) < 1e-2
+    assert _rel_err(dy, yr.grad) < 2e-2
+    assert _rel_err(dgamma, gr.grad) < 2e-2 and _rel_err(dbeta, br.grad) < 2e-2
+    assert _rel_err(dw, wr.grad) < 1e-2
