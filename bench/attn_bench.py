@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch  # noqa: E402
 
-SHAPES = [("gpt2-medium b16", 16, 1024, 16, True), ("vit-b/16 b256", 256, 197, 12, False), ("long 4k", 4, 4096, 16, True)]
+SHAPES = [("gpt2-medium b32", 32, 1024, 16, True), ("vit-b/16 b256", 256, 197, 12, False), ("long 4k", 4, 4096, 16, True),
+          ("long 4k full", 4, 4096, 16, False)]
 
 
 def _time(run, iters=20):

@@ -1,16 +1,23 @@
 // Fused multi-head attention (flash-style, head dim 64) on MFMA for packed QKV activations.
 //
-//   qkv : [B, S, 3, H, 64] bf16  (the output of the fused QKV projection, used in place)
-//   out : [B, S, H, 64]    bf16
-//   lse : [B, H, S]        fp32  log-sum-exp of the scaled scores (natural log), kept for backward
+//   qkv  : [B, S, 3, H, 64] bf16  (the output of the fused QKV projection, used in place)
+//   out  : [B, S, H, 64]    bf16
+//   lse  : [B, H, S]        fp32  log2-sum-exp2 of the scaled scores (log2 units), kept for backward
+//   dqkv : [B, S, 3, H, 64] bf16  (produced packed, so autograd never splits or concatenates)
 //
-// The S x S score matrix is never written.  A workgroup (4 waves) owns 64 queries (forward, dQ) or
-// 64 keys (dK/dV); each wave owns 16 of them and walks the other sequence in tiles of 64 staged in
-// LDS.  The MFMA orientation is always chosen so that the reduction index of the *next* product sits
-// on the accumulator registers of the current one: a 16x16 score tile leaves each lane with four
-// values of one column, which - packed to bf16 - is exactly the B-operand fragment of the following
-// MFMA once the other operand is read with the matching row permutation (transposing
-// ds_read_b64_tr_b16).  Softmax statistics are therefore per-lane scalars and P / dS never touch LDS.
+// The S x S score matrix is never written.  All three kernels share one structure:
+//   * a workgroup (4 waves) owns 128 rows of one sequence (queries in forward and dQ, keys in dK/dV), a wave 32 of
+//     them with the row on the MFMA lane (v_mfma_f32_32x32x16_bf16), and streams the other sequence in tiles of 64;
+//   * the MFMA orientation is chosen so that the reduction index of the *next* product sits on the accumulator
+//     registers of the current one: a 32x32 score tile leaves each lane with 16 values of one column, which - packed
+//     to bf16 - are the B-operand fragments of the following MFMAs once the other operand is read with the matching
+//     row permutation (transposing ds_read_b64_tr_b16).  P / dS never touch LDS, and whatever is constant per owned
+//     row (running maximum, row sum, log-sum-exp, delta) is a per-lane scalar;
+//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4, no staging registers) in a ring of three, two tiles ahead of
+//     the MFMAs, with one counted wait and one barrier per tile; one LDS image serves row reads and transposed reads;
+//   * the grid is one-dimensional and XCD-aware: consecutive workgroup ids go to the eight XCDs in turn, so the id is
+//     taken apart as (id % 8, id / 8) and all blocks of one (batch, head) land on one XCD, whose L2 then serves the
+//     tiles they share; under a causal mask the blocks with the most tiles are launched first.
 //
 // Not exercised by the reference (CNN only, /root/reference/src/main.py:49); serves ViT-B/16 and GPT-2.
 #include "common.h"
@@ -18,564 +25,632 @@
 
 #define AT_D 64
 #define AT_T 64           // tile length along the streamed sequence
-#define AT_PITCH 80       // padded LDS pitch (elements) for tiles read with the transposing load
+#define AT_BR 128         // rows of the owned sequence per workgroup
+#define AT_RING 3         // tiles in LDS per streamed operand
+#define AT_TILE (AT_T * AT_D)
 #define AT_NEG (-1.0e30f)
 
-typedef __attribute__((address_space(3))) s16x4 at_lds_s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void at_lds_void;
+typedef const __attribute__((address_space(1))) void at_global_cvoid;
 
 struct AttnArgs {
     const bf16* qkv;
     bf16* out;          // forward: O; backward kernels: unused
-    float* lse;
+    float* lse;         // [B, H, S], log2 units
     const bf16* dout;   // [B, S, H, 64]
     const bf16* o;      // [B, S, H, 64]
-    float* delta;       // [B, H, S]
+    float* delta;       // [B, H, S]: MINUS sum_d dO * O, written by the dQ kernel, read by the dK/dV kernel
     bf16* dqkv;         // [B, S, 3, H, 64]
     int B, S, H;
     float scale_log2;   // softmax scale * log2(e)
     float scale;
     int causal;
+    int nblk;           // blocks of AT_BR rows per sequence
 };
 
 __device__ __forceinline__ size_t qkv_off(const AttnArgs& p, int b, int s, int which, int h) {
     return (((static_cast<size_t>(b) * p.S + s) * 3 + which) * p.H + h) * AT_D;
 }
 
-// Staging of a 64 x 64 tile (row r from `src + r*stride` for r < valid, zeros otherwise) into LDS, either with
-// XOR-swizzled 16-byte chunks (row-major fragment reads) or in a plain padded layout (transposed reads).
-// The same staging split in two, so the global loads of tile t+1 are in flight while tile t is being
-// computed: tile_load right after the barrier that publishes tile t, tile_store_* after the next one.
-struct TileRegs {
-    bf16x8 v[2];
-};
-
-__device__ __forceinline__ TileRegs tile_load(const bf16* src, size_t stride, int valid, int tid) {
-    const int chunk = tid & 7, lrow = tid >> 3;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    TileRegs r;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = lrow + 32 * i;
-        r.v[i] = row < valid ? *reinterpret_cast<const bf16x8*>(src + row * stride + chunk * 8) : zero8;
-    }
-    return r;
-}
-
-__device__ __forceinline__ void tile_store_swz(bf16* dst, const TileRegs& r, int tid) {
-    const int chunk = tid & 7, lrow = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = lrow + 32 * i;
-        *reinterpret_cast<bf16x8*>(dst + row * AT_D + ((chunk ^ (row & 7)) << 3)) = r.v[i];
-    }
-}
-
-__device__ __forceinline__ void tile_store_pad(bf16* dst, const TileRegs& r, int tid) {
-    const int chunk = tid & 7, lrow = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = lrow + 32 * i;
-        *reinterpret_cast<bf16x8*>(dst + row * AT_PITCH + chunk * 8) = r.v[i];
-    }
-}
-
-// row-major fragment: lane (g, i) gets tile[row0 + i][32*ks + 8g .. +7]
-__device__ __forceinline__ bf16x8 frag_row(const bf16* tile, int row0, int ks, int lane) {
-    const int row = row0 + (lane & 15), kc = ks * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(tile + row * AT_D + ((kc ^ (row & 7)) << 3));
-}
-
-// transposed fragment: lane (g, i) gets tile[k0 + kappa(g, j)][col0 + i], kappa(g, j) = 4g + j (j < 4), 16 + 4g + j - 4
-__device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int k0, int col0, int lane) {
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const bf16* b0 = tile + (k0 + 4 * g + q) * AT_PITCH + col0 + 4 * pp;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_s16x4*)(b0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_s16x4*)(b0 + 16 * AT_PITCH));
-    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, r);
-}
-
-// two adjacent 16-row accumulator tiles -> bf16 B-operand fragment with the kappa row order
-__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
-    bf16x8 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r[e] = f32_to_bf16(a[e]);
-        r[e + 4] = f32_to_bf16(b[e]);
-    }
-    return r;
-}
-
-// 2^x by the bare hardware instruction: arguments here are <= ~8 and results below 2^-126 may flush to zero
+// 2^x by the bare hardware instruction: arguments here are bounded above and results below 2^-126 may flush to zero
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Reductions across the four 16-lane groups (same lane & 15) with the gfx950 row-swap instructions: after
-// v_permlane16_swap (v_permlane32_swap) of two copies of v, one copy holds the even rows (lower half) in every
-// row (half) and the other the odd rows (upper half), so one max / add finishes a butterfly step on the vector ALU;
-// the generic shuffle goes through the LDS crossbar instead (ds_bpermute, an order of magnitude more latency).
-__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// Exchange between lane l and lane l ^ 32 (the two lanes that share a row of a 32x32 accumulator tile): after
+// v_permlane32_swap of two copies of v, one copy holds the lower half's values in both halves and the other the
+// upper half's, so one max / add finishes the reduction on the vector ALU.
 __device__ __forceinline__ void swap_rows32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ float group_max(float v) {
+__device__ __forceinline__ float other_half_max(float v) {
     float a = v, b = v;
-    swap_rows16(a, b);
-    a = b = fmaxf(a, b);
     swap_rows32(a, b);
     return fmaxf(a, b);
 }
-__device__ __forceinline__ float group_sum(float v) {
+__device__ __forceinline__ float other_half_sum(float v) {
     float a = v, b = v;
-    swap_rows16(a, b);
-    a = b = a + b;
     swap_rows32(a, b);
     return a + b;
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward
+// LDS image of a 64 x 64 bf16 tile: [row][128 B], the 16-byte slots of row r XOR-ed with
+//   swz(r) = 4 * ((r >> 1) & 1) + ((r >> 2) & 3).
+// Row reads (ds_read_b128, 32 rows per instruction, serviced in the lane groups {0-3, 12-15, 20-27} and
+// {4-11, 16-19, 28-31} of each half wave): the 8 rows of equal parity in a group get 8 different slots.
+// Transposed reads (ds_read_b64_tr_b16, a half wave reads a 4-row x 32-column block): rows r and r + 2 differ in
+// bit 2 of the slot, rows r and r + 1 in the 128-byte parity, so the block covers all 64 banks once.
+// The image of an LDS-DMA piece is lane-linear (lane -> row lane / 8, slot lane % 8), so the permutation is applied
+// to the source address: slot s of row r receives chunk s ^ swz(r).  Rows past the end of the sequence repeat the
+// last row: their scores are masked, and the data stays finite.
 // ------------------------------------------------------------------------------------------------
-// QF query fragments of 16 per wave: a workgroup owns 64 * QF queries.  With QF = 2 every K / V fragment read
-// from LDS feeds two MFMAs, and the barriers and the staging of a tile are amortised over twice the work.
-template <int QF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    // K / V tiles are double-buffered in LDS: tile t + 1 is stored while tile t is being read, so one barrier
-    // per tile suffices and the LDS stores are a whole iteration ahead of their first read.
-    __shared__ __attribute__((aligned(16))) bf16 sKb[2][AT_T * AT_D];
-    __shared__ __attribute__((aligned(16))) bf16 sVb[2][AT_T * AT_PITCH];
+__device__ __forceinline__ uint32_t at_swz(uint32_t row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+struct TileDma {
+    uint32_t row[2];  // row of the tile this lane fetches in each of its wave's two pieces (8 pieces of 8 rows per tile)
+    uint32_t off[2];  // element offset of the lane's source chunk inside the row
+};
+
+__device__ __forceinline__ TileDma tile_dma_setup(int wave, int lane) {
+    TileDma d;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t row = (2 * wave + j) * 8 + (lane >> 3), slot = lane & 7;
+        d.row[j] = row;
+        d.off[j] = (slot ^ at_swz(row)) << 3;
+    }
+    return d;
+}
+
+// rows [r0, r0 + 64) of a [*, row_stride] matrix (clamped to last_row) into one tile; two LDS-DMA instructions per wave
+__device__ __forceinline__ void tile_dma_issue(const TileDma& d, const bf16* base, uint32_t row_stride, int r0, int last_row, bf16* tile,
+                                               int wave) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t off = static_cast<uint32_t>(min(r0 + static_cast<int>(d.row[j]), last_row)) * row_stride;
+        __builtin_amdgcn_global_load_lds((at_global_cvoid*)(base + off + d.off[j]), (at_lds_void*)(tile + (2 * wave + j) * 512), 16, 0, 0);
+    }
+}
+
+// Per-lane addressing of the fragment reads.
+struct FragAddr {
+    uint32_t row_off[4];  // row-major A fragment of k-step ks: element offset inside the tile for row lane % 32 (+ 32 per row tile)
+    uint32_t tr[2][2];    // transposed A fragment: LDS byte offset inside the tile for [column tile dt][4-row block blk]
+};
+
+__device__ __forceinline__ FragAddr frag_addr_setup(int lane) {
+    FragAddr f;
+    const int hi = lane >> 5, lq = lane & 31, l16 = lane & 15, half = (lane >> 4) & 1, piece = l16 & 3;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.row_off[ks] = lq * AT_D + (((2 * ks + hi) ^ at_swz(lq)) << 3);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const uint32_t row = 4 * hi + (l16 >> 2) + 8 * blk;
+            const uint32_t slot = (4 * dt + 2 * half + (piece >> 1)) ^ at_swz(row);
+            f.tr[dt][blk] = row * 128 + (slot << 4) + (piece & 1) * 8;
+        }
+    return f;
+}
+
+// A[i][k] = tile[32 rt + i][16 ks + k]: rows of the tile as the 32 x 16 A operand
+__device__ __forceinline__ bf16x8 frag_rows(const bf16* tile, const FragAddr& f, int rt, int ks) {
+    return *reinterpret_cast<const bf16x8*>(tile + rt * (32 * AT_D) + f.row_off[ks]);
+}
+
+// The eight transposed A fragments of one column tile dt: A[i][k] = tile[row(k)][32 dt + i] for the 16-row steps
+// (rt, j) of the tile, where row(k) follows the accumulator row order of the 32x32 MFMA (so packed accumulators are
+// the matching B operands).  Inline assembly: through the builtin the compiler cannot tell these reads from the
+// pending LDS-DMA writes and drains the whole DMA queue in front of them; their completion is awaited by hand.
+struct TrFrags {
+    s16x4 lo[2][2], hi[2][2];
+};
+
+__device__ __forceinline__ void frag_tr_issue(TrFrags& v, uint32_t tile_lds, const FragAddr& f, int dt) {
+    const uint32_t a0 = tile_lds + f.tr[dt][0], a1 = tile_lds + f.tr[dt][1];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v.lo[rt][j]) : "v"(a0), "n"((32 * rt + 16 * j) * 128) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v.hi[rt][j]) : "v"(a1), "n"((32 * rt + 16 * j) * 128) : "memory");
+        }
+}
+
+__device__ __forceinline__ void frag_tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ bf16x8 frag_tr_get(const TrFrags& v, int rt, int j) {
+    const s16x8 r = {v.lo[rt][j][0], v.lo[rt][j][1], v.lo[rt][j][2], v.lo[rt][j][3], v.hi[rt][j][0], v.hi[rt][j][1], v.hi[rt][j][2], v.hi[rt][j][3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// registers 8 j .. 8 j + 7 of an accumulator tile as the B operand of the next product
+__device__ __forceinline__ bf16x8 pack_half(const f32x16& a, int j) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f32_to_bf16(a[8 * j + e]);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((at_lds_void*)p)); }
+
+// acc^T[column][row] (two 32-column tiles, the row on the lane) times `mult` -> bf16 rows of 64 in a wave-private LDS
+// area (16-byte slots XOR-ed by row & 7), then whole 128-byte rows to global memory: dst(row) is the row's address.
+template <typename DstFn>
+__device__ __forceinline__ void store_rows32(bf16* so, const f32x16* acc, float mult, int lane, int rows_valid, DstFn dst) {
+    const int hi = lane >> 5, lq = lane & 31;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(acc[dt][4 * r4 + e] * mult);
+            *reinterpret_cast<bf16x4*>(so + lq * AT_D + (((4 * dt + r4) ^ (lq & 7)) << 3) + 4 * hi) = v;
+        }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + (lane >> 3), slot = lane & 7;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(so + row * AT_D + ((slot ^ (row & 7)) << 3));
+        if (row < rows_valid) *reinterpret_cast<bf16x8*>(dst(row) + slot * 8) = v;
+    }
+}
+
+// (block, batch * head) of a workgroup; false when the id is padding (batch * head rounded up to whole XCD rounds)
+__device__ __forceinline__ bool at_block_of(const AttnArgs& p, int& blk, int& b, int& h) {
+    const int xcd = blockIdx.x & 7, wid = blockIdx.x >> 3;
+    const int bh = (wid / p.nblk) * 8 + xcd;
+    if (bh >= p.B * p.H) return false;
+    blk = wid % p.nblk;
+    b = bh / p.H;
+    h = bh % p.H;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward:  S^T[key][q] = K . Q^T  (A = K rows, B = Q fragments in registers);  O^T[d][q] += V^T . P^T
+// A tile takes one fused multiply-add (softmax scale and running maximum), one exponential, one addition and half
+// a conversion per score; there is NO maximum in the common path: the maximum is taken on the first tile only, and
+// a later tile whose partial row sum exceeds 2^30 (a score ~30 octaves above the running maximum) is recomputed on
+// the careful path, which raises the maximum and rescales O.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) bf16 sKb[AT_RING][AT_TILE];
+    __shared__ __attribute__((aligned(1024))) bf16 sVb[AT_RING][AT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * (64 * QF);
-    int qrow[QF];  // this lane's queries
-#pragma unroll
-    for (int f = 0; f < QF; ++f) qrow[f] = q0 + (wave * QF + f) * 16 + i;
-    const size_t srow = static_cast<size_t>(3) * p.H * AT_D;  // elements between consecutive sequence positions
+    const int hi = lane >> 5, lq = lane & 31;
+    int qb, b, h;
+    if (!at_block_of(p, qb, b, h)) return;
+    if (p.causal) qb = p.nblk - 1 - qb;  // the last query blocks carry the most key tiles
+    const int q0 = qb * AT_BR, qw0 = q0 + 32 * wave, qrow = qw0 + lq;
+    const uint32_t srow = static_cast<uint32_t>(3 * p.H * AT_D);
 
-    bf16x8 qf[QF][2];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16* qp = p.qkv + qkv_off(p, b, min(qrow[f], p.S - 1), 0, h);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[f][ks] = qrow[f] < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
-    }
-    // The softmax denominators are accumulated by the matrix unit as well: one more MFMA per 32 keys against a
-    // fragment of ones leaves sum_k P[k][query] in every row of `l` (all four registers of every lane group hold
-    // the query's total), which takes 16 additions and a cross-lane reduction per tile off the vector ALU.
-    f32x4 o[QF][4], l[QF];
-    float m[QF];
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = f32_to_bf16(1.f);
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[f][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m[f] = AT_NEG;
-        l[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    // number of key tiles of the workgroup and of this wave (a wave without a valid query computes nothing)
+    const int nt = p.causal ? min(p.S - 1, q0 + AT_BR - 1) / AT_T + 1 : (p.S + AT_T - 1) / AT_T;
+    const int wave_nt = qw0 >= p.S ? 0 : (p.causal ? min(p.S - 1, qw0 + 31) / AT_T + 1 : nt);
+    const bf16* kbase = p.qkv + qkv_off(p, b, 0, 1, h);
+    const bf16* vbase = p.qkv + qkv_off(p, b, 0, 2, h);
+    const TileDma dma = tile_dma_setup(wave, lane);
+    const FragAddr fa = frag_addr_setup(lane);
 
-    const int kend = p.causal ? min(p.S, q0 + 64 * QF) : p.S;
-    // keys this wave needs under a causal mask: up to its own last query (wave-uniform); later tiles are skipped
-    // (a wave whose first query lies beyond S has nothing to do at all)
-    const int wave_kend = q0 + wave * QF * 16 >= p.S ? 0 : (p.causal ? min(p.S, q0 + (wave * QF + QF) * 16) : p.S);
-    TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
-    TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
-    tile_store_swz(sKb[0], rk, tid);
-    tile_store_pad(sVb[0], rv, tid);
-    if (AT_T < kend) {
-        rk = tile_load(p.qkv + qkv_off(p, b, AT_T, 1, h), srow, p.S - AT_T, tid);
-        rv = tile_load(p.qkv + qkv_off(p, b, AT_T, 2, h), srow, p.S - AT_T, tid);
+    bf16x8 qf[4];  // B operand of S^T: Q[q][16 ks + 8 hi .. + 7]
+    {
+        const bf16* qp = p.qkv + qkv_off(p, b, min(qrow, p.S - 1), 0, h) + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
     }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < nt) {
+            tile_dma_issue(dma, kbase, srow, t * AT_T, p.S - 1, sKb[t], wave);
+            tile_dma_issue(dma, vbase, srow, t * AT_T, p.S - 1, sVb[t], wave);
+        }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
+    float lsum = 0.f;  // this lane's share (32 of every 64 keys) of the query's row sum
+    float nm = 0.f;    // minus the running maximum, in log2 units
+    const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;  // last key this lane's query attends to
+    const uint32_t sv_lds = lds_addr(&sVb[0][0]);
+
     int buf = 0;
-    for (int k0 = 0; k0 < kend; k0 += AT_T, buf ^= 1) {
-        // tile k0 is complete in buffer `buf`, and every wave is done reading the other buffer (tile k0 - 64)
-        __syncthreads();
-        const bf16* sK = sKb[buf];
-        const bf16* sV = sVb[buf];
-        if (k0 + AT_T < kend) {  // registers hold tile k0 + 64 (loaded during the previous iteration): park it in LDS
-            tile_store_swz(sKb[buf ^ 1], rk, tid);
-            tile_store_pad(sVb[buf ^ 1], rv, tid);
-            if (k0 + 2 * AT_T < kend) {  // and fetch the one after it, in flight during this tile's MFMAs
-                rk = tile_load(p.qkv + qkv_off(p, b, k0 + 2 * AT_T, 1, h), srow, p.S - k0 - 2 * AT_T, tid);
-                rv = tile_load(p.qkv + qkv_off(p, b, k0 + 2 * AT_T, 2, h), srow, p.S - k0 - 2 * AT_T, tid);
-            }
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = t * AT_T;
+        // this wave's pieces of tile t have landed (those of tile t + 1 may still be in flight); after the barrier
+        // everybody's have, and nobody reads tile t - 1 any more: its buffer takes tile t + 2
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 2 < nt) {
+            const int nb = buf == 0 ? AT_RING - 1 : buf - 1;
+            tile_dma_issue(dma, kbase, srow, k0 + 2 * AT_T, p.S - 1, sKb[nb], wave);
+            tile_dma_issue(dma, vbase, srow, k0 + 2 * AT_T, p.S - 1, sVb[nb], wave);
         }
-        if (k0 >= wave_kend) continue;  // every key of this tile is masked for every query of this wave
-        f32x4 s[QF][4];
+        const int cur = buf;
+        buf = buf == AT_RING - 1 ? 0 : buf + 1;
+        if (t >= wave_nt) continue;
+        const bf16* sK = sKb[cur];
+        const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T - 1 > qw0);
+        f32x16 acc[2];
+        // scores of the tile -> probabilities relative to the running maximum, in place; returns the lane's partial row sum
+        auto score_tile = [&](const bool careful) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int f = 0; f < QF; ++f) s[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 16; ++e) acc[kt][e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = frag_row(sK, t * 16, ks, lane);
-#pragma unroll
-                for (int f = 0; f < QF; ++f) s[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][ks], s[f][t], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sK, fa, kt, ks), qf[ks], acc[kt], 0, 0, 0);
             }
-        }
-        // Only the last key tile (keys beyond S) and, with a causal mask, the tiles that reach past the first
-        // query of the workgroup need per-element masking; the branch is uniform for the workgroup.
-        const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T > q0);
-#pragma unroll
-        for (int f = 0; f < QF; ++f) {
-            float mx = AT_NEG;  // maximum of the raw scores; the softmax scale (> 0) is folded into the exponent's fma
             if (masked) {
+                const int rel = key_limit - k0 - 4 * hi;  // last valid key offset inside the tile, minus this half's share
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int key = k0 + t * 16 + g * 4 + e;
-                        const bool ok = key < p.S && (!p.causal || key <= qrow[f]);
-                        s[f][t][e] = ok ? s[f][t][e] : AT_NEG;
-                        mx = fmaxf(mx, s[f][t][e]);
+                    for (int r = 0; r < 16; ++r) acc[kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= rel ? acc[kt][r] : AT_NEG;
+            }
+            if (careful) {
+                float mx = AT_NEG;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[kt][r]);
+                mx = other_half_max(mx) * p.scale_log2;
+                // first tile: the maximum becomes the reference whatever its sign; later: only ever raised
+                const float cand = mx < -1.0e29f ? -nm : mx;
+                const float m_new = t == 0 ? cand : fmaxf(cand, -nm);
+                if (t != 0) {
+                    const float alpha = fast_exp2(-nm - m_new);
+                    lsum *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        o[0][e] *= alpha;
+                        o[1][e] *= alpha;
                     }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][t][e]);
-            }
-            mx = group_max(mx) * p.scale_log2;
-            // The running maximum is raised only when a score exceeds it by more than 2^6: probabilities are then
-            // bounded by 64 instead of 1 (harmless in fp32 / bf16) and the rescaling of the output accumulators,
-            // which costs a round trip through the vector ALU, is skipped for most tiles.  Wave-uniform decision.
-            const bool raise = __any(mx > m[f] + 6.0f);
-            if (raise) {
-                const float mn = fmaxf(m[f], mx);
-                const float alpha = fast_exp2(m[f] - mn);
-                l[f][0] *= alpha;
-                m[f] = mn;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[f][dt][e] *= alpha;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    s[f][t][e] = fast_exp2(fmaf(s[f][t][e], p.scale_log2, -m[f]));  // masked scores are -1e30: 2^-huge = 0
-        }
-        bf16x8 pf[QF][2];
-#pragma unroll
-        for (int f = 0; f < QF; ++f)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                pf[f][kp] = pack_pair(s[f][2 * kp], s[f][2 * kp + 1]);
-                l[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[f][kp], l[f], 0, 0, 0);
-            }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                const bf16x8 vf = frag_tr(sV, kp * 32, dt * 16, lane);
-#pragma unroll
-                for (int f = 0; f < QF; ++f) o[f][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[f][kp], o[f][dt], 0, 0, 0);
-            }
-    }
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        if (qrow[f] < p.S) {
-            const float lt = l[f][0];
-            const float inv = lt > 0.f ? 1.f / lt : 0.f;
-            bf16* op = p.out + ((static_cast<size_t>(b) * p.S + qrow[f]) * p.H + h) * AT_D;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(o[f][dt][e] * inv);
-                *reinterpret_cast<bf16x4*>(op + dt * 16 + g * 4) = v;
-            }
-            if (g == 0)
-                p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow[f]] = (m[f] + log2f(fmaxf(lt, 1e-30f))) * 0.6931471805599453f;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// delta[b,h,s] = sum_d dO * O   (8 lanes x 16 bytes per (b, s, h) row of 64: a wave reads 8 rows = 1 KB per load)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
-    const long long rows = static_cast<long long>(p.B) * p.S * p.H;
-    const long long row = blockIdx.x * 32ll + (threadIdx.x >> 3);
-    const int part = threadIdx.x & 7;
-    float v = 0.f;
-    if (row < rows) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.dout + row * AT_D + part * 8);
-        const bf16x8 c = *reinterpret_cast<const bf16x8*>(p.o + row * AT_D + part * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v += bf16_to_f32(a[e]) * bf16_to_f32(c[e]);
-    }
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    if (part == 0 && row < rows) {
-        const int h = static_cast<int>(row % p.H);
-        const long long bs = row / p.H;
-        const int s = static_cast<int>(bs % p.S), b = static_cast<int>(bs / p.S);
-        p.delta[(static_cast<size_t>(b) * p.H + h) * p.S + s] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dK, dV: workgroup = 64 keys, wave = 16 keys (key on the lane), streams query tiles.
-//   S[q][key] = Q K^T, dP[q][key] = dO V^T  (accumulators: q on registers, key on lanes)
-//   dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16 sQ[AT_T * AT_D];
-    __shared__ __attribute__((aligned(16))) bf16 sQt[AT_T * AT_PITCH];
-    __shared__ __attribute__((aligned(16))) bf16 sDO[AT_T * AT_D];
-    __shared__ __attribute__((aligned(16))) bf16 sDOt[AT_T * AT_PITCH];
-    __shared__ float sLse[AT_T], sDelta[AT_T];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int k0 = blockIdx.x * 64;
-    const int key = k0 + wave * 16 + i;
-    const size_t srow = static_cast<size_t>(3) * p.H * AT_D;
-    const size_t orow = static_cast<size_t>(p.H) * AT_D;
-
-    bf16x8 kf[2], vf[2];  // B operands: K^T / V^T fragments of this lane's key
-    {
-        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int kc = min(key, p.S - 1);
-        const bf16* kp = p.qkv + qkv_off(p, b, kc, 1, h);
-        const bf16* vp = p.qkv + qkv_off(p, b, kc, 2, h);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            kf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(kp + ks * 32 + g * 8) : zero8;
-            vf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(vp + ks * 32 + g * 8) : zero8;
-        }
-    }
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int qstart = p.causal ? k0 : 0;  // queries before the first key of this tile never attend to it
-    TileRegs rq, rdo;
-    float r_lse = 0.f, r_delta = 0.f;
-    auto prefetch = [&](int q0) {
-        rq = tile_load(p.qkv + qkv_off(p, b, q0, 0, h), srow, p.S - q0, tid);
-        rdo = tile_load(p.dout + ((static_cast<size_t>(b) * p.S + q0) * p.H + h) * AT_D, orow, p.S - q0, tid);
-        if (tid < AT_T) {
-            const int qq = q0 + tid;
-            const size_t off = (static_cast<size_t>(b) * p.H + h) * p.S + min(qq, p.S - 1);
-            r_lse = qq < p.S ? p.lse[off] * 1.4426950408889634f : 0.f;
-            r_delta = qq < p.S ? p.delta[off] : 0.f;
-        }
-    };
-    if (qstart < p.S) prefetch(qstart);
-    for (int q0 = qstart; q0 < p.S; q0 += AT_T) {
-        __syncthreads();  // every wave is done with the previous tile
-        tile_store_swz(sQ, rq, tid);
-        tile_store_pad(sQt, rq, tid);
-        tile_store_swz(sDO, rdo, tid);
-        tile_store_pad(sDOt, rdo, tid);
-        if (tid < AT_T) {
-            sLse[tid] = r_lse;
-            sDelta[tid] = r_delta;
-        }
-        __syncthreads();
-        if (q0 + AT_T < p.S) prefetch(q0 + AT_T);  // in flight during this tile's MFMAs
-        // per-element masking only where it can matter: queries or keys beyond S, the causal diagonal (uniform)
-        const bool masked = (q0 + AT_T > p.S) || (k0 + AT_T > p.S) || (p.causal && q0 < k0 + AT_T);
-        f32x4 pt[4], ds[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sQ, t * 16, ks, lane), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sDO, t * 16, ks, lane), vf[ks], dp, 0, 0, 0);
-            }
-            if (masked) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ql = t * 16 + g * 4 + e, qq = q0 + ql;
-                    const bool ok = qq < p.S && key < p.S && (!p.causal || key <= qq);
-                    const float pv = ok ? fast_exp2(s[e] * p.scale_log2 - sLse[ql]) : 0.f;
-                    pt[t][e] = pv;
-                    ds[t][e] = pv * (dp[e] - sDelta[ql]);
                 }
-            } else {
+                nm = -m_new;
+            }
+            float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ql = t * 16 + g * 4 + e;
-                    const float pv = fast_exp2(s[e] * p.scale_log2 - sLse[ql]);
-                    pt[t][e] = pv;
-                    ds[t][e] = pv * (dp[e] - sDelta[ql]);
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[kt][r] = fast_exp2(fmaf(acc[kt][r], p.scale_log2, nm));  // masked scores are -1e30: 2^-huge = 0
+                    sum += acc[kt][r];
                 }
-            }
+            return sum;
+        };
+        float ls;
+        if (t == 0) {
+            ls = score_tile(true);
+        } else {
+            ls = score_tile(false);
+            if (__builtin_expect(__any(!(ls <= 1073741824.f)), 0)) ls = score_tile(true);
         }
+        lsum += ls;
+        bf16x8 pb[2][2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sDOt, kp * 32, dt * 16, lane),
-                                                                 pack_pair(pt[2 * kp], pt[2 * kp + 1]), dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQt, kp * 32, dt * 16, lane),
-                                                                 pack_pair(ds[2 * kp], ds[2 * kp + 1]), dk[dt], 0, 0, 0);
-            }
-    }
-    if (key < p.S) {
-        bf16* dkp = p.dqkv + qkv_off(p, b, key, 1, h);
-        bf16* dvp = p.dqkv + qkv_off(p, b, key, 2, h);
+            for (int j = 0; j < 2; ++j) pb[kt][j] = pack_half(acc[kt], j);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            bf16x4 a, c;
+        for (int dt = 0; dt < 2; ++dt) {
+            TrFrags vf;
+            frag_tr_issue(vf, sv_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
+            frag_tr_wait();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[e] = f32_to_bf16(dk[dt][e] * p.scale);
-                c[e] = f32_to_bf16(dv[dt][e]);
-            }
-            *reinterpret_cast<bf16x4*>(dkp + dt * 16 + g * 4) = a;
-            *reinterpret_cast<bf16x4*>(dvp + dt * 16 + g * 4) = c;
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf, kt, j), pb[kt][j], o[dt], 0, 0, 0);
         }
     }
+    // every wave is done with the K / V tiles: the first buffers become the staging area of the output rows
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const float lt = other_half_sum(lsum);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    if (hi == 0 && qrow < p.S) p.lse[(static_cast<size_t>(b) * p.H + h) * p.S + qrow] = log2f(fmaxf(lt, 1e-30f)) - nm;
+    bf16* orow0 = p.out + ((static_cast<size_t>(b) * p.S + qw0) * p.H + h) * AT_D;
+    const size_t ostride = static_cast<size_t>(p.H) * AT_D;
+    store_rows32(&sKb[0][0] + wave * (32 * AT_D), o, inv, lane, p.S - qw0, [&](int row) { return orow0 + row * ostride; });
 }
 
 // ------------------------------------------------------------------------------------------------
-// dQ: workgroup = 64 queries, wave = 16 queries (query on the lane), streams key tiles.
-//   S^T[key][q] = K Q^T, dP^T[key][q] = V dO^T;  dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+// dQ (and delta): workgroup = 128 queries, the query on the lane, streams K / V tiles.
+//   S^T[key][q] = K . Q^T,  dP^T[key][q] = V . dO^T - delta[q]  (delta goes in as the initial accumulator: 16 equal
+//   registers per lane, set once),  dS^T = P^T * dP^T,  dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+// delta[q] = sum_d dO[q][d] O[q][d] is formed from the dO fragments the wave holds anyway and written (negated) for
+// the dK/dV kernel, which runs after this one.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16 sK[AT_T * AT_D];
-    __shared__ __attribute__((aligned(16))) bf16 sKt[AT_T * AT_PITCH];
-    __shared__ __attribute__((aligned(16))) bf16 sV[AT_T * AT_D];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) bf16 sKb[AT_RING][AT_TILE];
+    __shared__ __attribute__((aligned(1024))) bf16 sVb[AT_RING][AT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * 64;
-    const int qrow = q0 + wave * 16 + i;
-    const size_t srow = static_cast<size_t>(3) * p.H * AT_D;
+    const int hi = lane >> 5, lq = lane & 31;
+    int qb, b, h;
+    if (!at_block_of(p, qb, b, h)) return;
+    if (p.causal) qb = p.nblk - 1 - qb;
+    const int q0 = qb * AT_BR, qw0 = q0 + 32 * wave, qrow = qw0 + lq;
+    const uint32_t srow = static_cast<uint32_t>(3 * p.H * AT_D);
+    const int nt = p.causal ? min(p.S - 1, q0 + AT_BR - 1) / AT_T + 1 : (p.S + AT_T - 1) / AT_T;
+    const int wave_nt = qw0 >= p.S ? 0 : (p.causal ? min(p.S - 1, qw0 + 31) / AT_T + 1 : nt);
+    const bf16* kbase = p.qkv + qkv_off(p, b, 0, 1, h);
+    const bf16* vbase = p.qkv + qkv_off(p, b, 0, 2, h);
+    const TileDma dma = tile_dma_setup(wave, lane);
+    const FragAddr fa = frag_addr_setup(lane);
 
-    bf16x8 qf[2], dof[2];
-    float lse2 = 0.f, delta = 0.f;
+    bf16x8 qf[4], dof[4];
+    float nl = 0.f;    // minus the row's log-sum-exp (log2 units)
+    f32x16 ndelta;
     {
-        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
         const int qc = min(qrow, p.S - 1);
-        const bf16* qp = p.qkv + qkv_off(p, b, qc, 0, h);
-        const bf16* dop = p.dout + ((static_cast<size_t>(b) * p.S + qc) * p.H + h) * AT_D;
+        const bf16* qp = p.qkv + qkv_off(p, b, qc, 0, h) + 8 * hi;
+        const size_t orow = ((static_cast<size_t>(b) * p.S + qc) * p.H + h) * AT_D + 8 * hi;
+        float dl = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = qrow < p.S ? *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8) : zero8;
-            dof[ks] = qrow < p.S ? *reinterpret_cast<const bf16x8*>(dop + ks * 32 + g * 8) : zero8;
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + orow + 16 * ks);
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + orow + 16 * ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += bf16_to_f32(dof[ks][e]) * bf16_to_f32(ov[e]);
         }
-        if (qrow < p.S) {
-            const size_t off = (static_cast<size_t>(b) * p.H + h) * p.S + qrow;
-            lse2 = p.lse[off] * 1.4426950408889634f;
-            delta = p.delta[off];
+        dl = other_half_sum(dl);
+        const size_t off = (static_cast<size_t>(b) * p.H + h) * p.S + qc;
+        if (hi == 0 && qrow < p.S) p.delta[off] = -dl;
+        nl = -p.lse[off];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ndelta[e] = -dl;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < nt) {
+            tile_dma_issue(dma, kbase, srow, t * AT_T, p.S - 1, sKb[t], wave);
+            tile_dma_issue(dma, vbase, srow, t * AT_T, p.S - 1, sVb[t], wave);
+        }
+    f32x16 dq[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = 0.f;
+    const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;
+    const uint32_t sk_lds = lds_addr(&sKb[0][0]);
+
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = t * AT_T;
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 2 < nt) {
+            const int nb = buf == 0 ? AT_RING - 1 : buf - 1;
+            tile_dma_issue(dma, kbase, srow, k0 + 2 * AT_T, p.S - 1, sKb[nb], wave);
+            tile_dma_issue(dma, vbase, srow, k0 + 2 * AT_T, p.S - 1, sVb[nb], wave);
+        }
+        const int cur = buf;
+        buf = buf == AT_RING - 1 ? 0 : buf + 1;
+        if (t >= wave_nt) continue;
+        const bf16* sK = sKb[cur];
+        const bf16* sV = sVb[cur];
+        const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T - 1 > qw0);
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sK, fa, kt, ks), qf[ks], s[kt], 0, 0, 0);
+                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sV, fa, kt, ks), dof[ks], ks == 0 ? ndelta : dp[kt], 0, 0, 0);
+            }
+        }
+        if (masked) {
+            const int rel = key_limit - k0 - 4 * hi;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= rel ? s[kt][r] : AT_NEG;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = fast_exp2(fmaf(s[kt][r], p.scale_log2, nl)) * dp[kt][r];
+        bf16x8 dsb[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dsb[kt][j] = pack_half(s[kt], j);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            TrFrags kf;
+            frag_tr_issue(kf, sk_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
+            frag_tr_wait();
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(kf, kt, j), dsb[kt][j], dq[dt], 0, 0, 0);
         }
     }
-    f32x4 dq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    bf16* drow0 = p.dqkv + qkv_off(p, b, min(qw0, p.S - 1), 0, h);
+    store_rows32(&sKb[0][0] + wave * (32 * AT_D), dq, p.scale, lane, p.S - qw0, [&](int row) { return drow0 + static_cast<size_t>(row) * srow; });
+}
 
-    const int kend = p.causal ? min(p.S, q0 + 64) : p.S;
-    TileRegs rk = tile_load(p.qkv + qkv_off(p, b, 0, 1, h), srow, p.S, tid);
-    TileRegs rv = tile_load(p.qkv + qkv_off(p, b, 0, 2, h), srow, p.S, tid);
-    for (int k0 = 0; k0 < kend; k0 += AT_T) {
-        __syncthreads();  // every wave is done with the previous tile
-        tile_store_swz(sK, rk, tid);
-        tile_store_pad(sKt, rk, tid);
-        tile_store_swz(sV, rv, tid);
-        __syncthreads();
-        if (k0 + AT_T < kend) {  // next tile: in flight during this tile's MFMAs
-            rk = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 1, h), srow, p.S - k0 - AT_T, tid);
-            rv = tile_load(p.qkv + qkv_off(p, b, k0 + AT_T, 2, h), srow, p.S - k0 - AT_T, tid);
+// ------------------------------------------------------------------------------------------------
+// dK, dV: workgroup = 128 keys, the key on the lane, streams Q / dO tiles (and their log-sum-exp / delta rows).
+//   S[q][key] = Q . K^T,  dP[q][key] = dO . V^T - delta[q]  (the tile's -delta values are the initial accumulator),
+//   dV^T[d][key] += dO^T[d][q] . P[q][key],   dK^T[d][key] += Q^T[d][q] . dS[q][key]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(1024))) bf16 sQb[AT_RING][AT_TILE];
+    __shared__ __attribute__((aligned(1024))) bf16 sDOb[AT_RING][AT_TILE];
+    __shared__ __attribute__((aligned(1024))) float sRow[AT_RING][4][AT_T];  // per tile: lse, -delta, and two unused rows (waves 2, 3)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    int kb, b, h;
+    if (!at_block_of(p, kb, b, h)) return;  // under a causal mask the first key blocks carry the most query tiles: natural order
+    const int k0 = kb * AT_BR, kw0 = k0 + 32 * wave, key = kw0 + lq;
+    const uint32_t srow = static_cast<uint32_t>(3 * p.H * AT_D), orow = static_cast<uint32_t>(p.H * AT_D);
+    const int nt = (p.S + AT_T - 1) / AT_T;
+    const int t0 = p.causal ? k0 / AT_T : 0;                             // first query tile that reaches this key block
+    const int wave_t0 = kw0 >= p.S ? nt : (p.causal ? kw0 / AT_T : 0);  // ... and this wave's keys
+    const bf16* qbase = p.qkv + qkv_off(p, b, 0, 0, h);
+    const bf16* dobase = p.dout + (static_cast<size_t>(b) * p.S * p.H + h) * AT_D;
+    const float* rowbase = (wave & 1 ? p.delta : p.lse) + (static_cast<size_t>(b) * p.H + h) * p.S;
+    const TileDma dma = tile_dma_setup(wave, lane);
+    const FragAddr fa = frag_addr_setup(lane);
+
+    bf16x8 kf[4], vf[4];  // B operands: K^T / V^T fragments of this lane's key
+    {
+        const int kc = min(key, p.S - 1);
+        const bf16* kp = p.qkv + qkv_off(p, b, kc, 1, h) + 8 * hi;
+        const bf16* vp = p.qkv + qkv_off(p, b, kc, 2, h) + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
         }
-        const bool masked = (k0 + AT_T > p.S) || (q0 + 64 > p.S) || (p.causal && k0 + AT_T > q0);
-        f32x4 ds[4];
+    }
+    auto issue = [&](int t, int slot) {
+        tile_dma_issue(dma, qbase, srow, t * AT_T, p.S - 1, sQb[slot], wave);
+        tile_dma_issue(dma, dobase, orow, t * AT_T, p.S - 1, sDOb[slot], wave);
+        // 64 floats of lse (even waves) or -delta (odd waves): one 4-byte LDS-DMA per lane
+        __builtin_amdgcn_global_load_lds((at_global_cvoid*)(rowbase + min(t * AT_T + lane, p.S - 1)), (at_lds_void*)&sRow[slot][wave][0], 4, 0, 0);
+    };
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i)
+        if (t0 + i < nt) issue(t0 + i, i);
+    f32x16 dk[2], dv[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sK, t * 16, ks, lane), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(sV, t * 16, ks, lane), dof[ks], dp, 0, 0, 0);
-            }
-            if (masked) {
+    for (int e = 0; e < 16; ++e) dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f;
+    const uint32_t sq_lds = lds_addr(&sQb[0][0]), sdo_lds = lds_addr(&sDOb[0][0]);
+
+    int buf = 0;
+    for (int t = t0; t < nt; ++t) {
+        const int q0 = t * AT_T;
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 2 < nt) issue(t + 2, buf == 0 ? AT_RING - 1 : buf - 1);
+        const int cur = buf;
+        buf = buf == AT_RING - 1 ? 0 : buf + 1;
+        if (t < wave_t0) continue;
+        const bf16* sQ = sQb[cur];
+        const bf16* sDO = sDOb[cur];
+        // per-element masking only where it can matter: queries beyond S, the causal diagonal (wave-uniform)
+        const bool masked = (q0 + AT_T > p.S) || (p.causal && q0 < kw0 + 31);
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // accumulator register r of this lane is query 32 qt + (r & 3) + 8 (r >> 2) + 4 hi of the tile
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(&sRow[cur][1][32 * qt + 8 * r4 + 4 * hi]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + t * 16 + g * 4 + e;
-                    const bool ok = key < p.S && qrow < p.S && (!p.causal || key <= qrow);
-                    const float pv = ok ? fast_exp2(s[e] * p.scale_log2 - lse2) : 0.f;
-                    ds[t][e] = pv * (dp[e] - delta);
+                    dp[qt][4 * r4 + e] = nd[e];
+                    s[qt][4 * r4 + e] = 0.f;
                 }
-            } else {
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ds[t][e] = fast_exp2(s[e] * p.scale_log2 - lse2) * (dp[e] - delta);
+            for (int ks = 0; ks < 4; ++ks) {
+                s[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sQ, fa, qt, ks), kf[ks], s[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sDO, fa, qt, ks), vf[ks], dp[qt], 0, 0, 0);
+            }
+        }
+        if (masked) {
+            const int lo = (p.causal ? key : 0) - q0 - 4 * hi, up = p.S - 1 - q0 - 4 * hi;  // valid query offsets: [lo, up]
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qo = 32 * qt + (r & 3) + 8 * (r >> 2);
+                    s[qt][r] = (qo >= lo && qo <= up) ? s[qt][r] : AT_NEG;
+                }
+        }
+        bf16x8 pb[2][2], dsb[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 l2 = *reinterpret_cast<const f32x4*>(&sRow[cur][0][32 * qt + 8 * r4 + 4 * hi]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = fast_exp2(fmaf(s[qt][4 * r4 + e], p.scale_log2, -l2[e]));
+                    s[qt][4 * r4 + e] = pv;
+                    dp[qt][4 * r4 + e] *= pv;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                pb[qt][j] = pack_half(s[qt], j);
+                dsb[qt][j] = pack_half(dp[qt], j);
             }
         }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 2; ++dt) {
+            TrFrags dof, qf;
+            frag_tr_issue(dof, sdo_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
+            frag_tr_issue(qf, sq_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
+            frag_tr_wait();
 #pragma unroll
-            for (int kp = 0; kp < 2; ++kp)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sKt, kp * 32, dt * 16, lane),
-                                                                 pack_pair(ds[2 * kp], ds[2 * kp + 1]), dq[dt], 0, 0, 0);
-    }
-    if (qrow < p.S) {
-        bf16* dqp = p.dqkv + qkv_off(p, b, qrow, 0, h);
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            bf16x4 a;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = f32_to_bf16(dq[dt][e] * p.scale);
-            *reinterpret_cast<bf16x4*>(dqp + dt * 16 + g * 4) = a;
+                for (int j = 0; j < 2; ++j) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(dof, qt, j), pb[qt][j], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(qf, qt, j), dsb[qt][j], dk[dt], 0, 0, 0);
+                }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    bf16* so = &sQb[0][0] + wave * (32 * AT_D);
+    bf16* krow0 = p.dqkv + qkv_off(p, b, min(kw0, p.S - 1), 1, h);
+    bf16* vrow0 = p.dqkv + qkv_off(p, b, min(kw0, p.S - 1), 2, h);
+    store_rows32(so, dk, p.scale, lane, p.S - kw0, [&](int row) { return krow0 + static_cast<size_t>(row) * srow; });
+    store_rows32(so, dv, 1.f, lane, p.S - kw0, [&](int row) { return vrow0 + static_cast<size_t>(row) * srow; });
 }
 
 static int attn_check(int B, int S, int H, int D) {
     if (B <= 0 || S <= 0 || H <= 0 || D != AT_D) return -1;
-    if (static_cast<long long>(B) * H > 65535ll) return -1;  // grid.y limit
+    // 32-bit element offsets inside one batch element's [S, 3, H, 64] slab, and a grid of at most 2^31 - 1 workgroups
+    if (static_cast<long long>(S) * 3 * H * D >= (1ll << 31)) return -1;
+    if (static_cast<long long>(pdt_cdiv(S, AT_BR)) * 8 * pdt_cdiv(static_cast<long long>(B) * H, 8) >= (1ll << 31)) return -1;
     if (static_cast<long long>(B) * S * 3 * H * D >= (1ll << 40)) return -1;
     return 0;
 }
 
-PDT_API int pdt_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int D, float scale, int causal,
-                              void* stream) {
-    if (attn_check(B, S, H, D) != 0) return -1;
+static AttnArgs attn_args(int B, int S, int H, float scale, int causal) {
     AttnArgs a = {};
-    a.qkv = static_cast<const bf16*>(qkv);
-    a.out = static_cast<bf16*>(out);
-    a.lse = lse;
     a.B = B; a.S = S; a.H = H;
     a.scale = scale;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.causal = causal;
-    // 32 queries per wave pay for short non-causal sequences (ViT: +12 %); on long or causal ones the higher
-    // register footprint costs more occupancy than the halved LDS traffic gains (measured: bench/attn_bench.py)
-    static int qf_env = -1;
-    if (qf_env < 0) {
-        const char* e = getenv("PDT_ATTN_QF");
-        qf_env = e ? atoi(e) : 0;
-    }
-    const int qf = qf_env ? qf_env : ((S > 64 && S <= 512 && !causal) ? 2 : 1);
-    if (qf == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(pdt_cdiv(S, 128), B * H), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    a.nblk = pdt_cdiv(S, AT_BR);
+    return a;
+}
+
+static dim3 attn_grid(const AttnArgs& a) { return dim3(static_cast<unsigned>(a.nblk) * 8u * static_cast<unsigned>(pdt_cdiv(a.B * a.H, 8))); }
+
+PDT_API int pdt_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int D, float scale, int causal,
+                              void* stream) {
+    if (attn_check(B, S, H, D) != 0) return -1;
+    AttnArgs a = attn_args(B, S, H, scale, causal);
+    a.qkv = static_cast<const bf16*>(qkv);
+    a.out = static_cast<bf16*>(out);
+    a.lse = lse;
+    hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(a), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return pdt_launch_status();
 }
 
+// `delta` is scratch of B * H * S floats: written by the dQ kernel, consumed by the dK/dV kernel behind it.
 PDT_API int pdt_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
                               int B, int S, int H, int D, float scale, int causal, void* stream) {
     if (attn_check(B, S, H, D) != 0) return -1;
-    AttnArgs a = {};
+    AttnArgs a = attn_args(B, S, H, scale, causal);
     a.qkv = static_cast<const bf16*>(qkv);
     a.o = static_cast<const bf16*>(o);
     a.dout = static_cast<const bf16*>(dout);
     a.lse = const_cast<float*>(lse);
     a.delta = delta;
     a.dqkv = static_cast<bf16*>(dqkv);
-    a.B = B; a.S = S; a.H = H;
-    a.scale = scale;
-    a.scale_log2 = scale * 1.4426950408889634f;
-    a.causal = causal;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long rows = static_cast<long long>(B) * S * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(pdt_cdiv(rows, 32)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(pdt_cdiv(S, 64), B * H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, attn_grid(a), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(a), dim3(256), 0, s, a);
     return pdt_launch_status();
 }
