@@ -1,6 +1,6 @@
 """Fused attention kernels alone: forward and backward time on the GPT-2 medium and ViT-B/16 shapes.
 
-    python bench/attn_bench.py
+    python bench/attn_bench.py [substring of a shape name]
 """
 from __future__ import annotations
 
@@ -34,6 +34,8 @@ def main():
     dev = torch.device("cuda", 0)
     print(f"{'shape':<18}{'fwd us':>9}{'TF/s':>7}{'bwd us':>9}{'TF/s':>7}   (FLOPs: 4 B H S^2 64 forward, 2.5x backward; halved when causal)")
     for name, b, s, h, causal in SHAPES:
+        if len(sys.argv) > 1 and sys.argv[1] not in name:
+            continue
         qkv = torch.randn(b, s, 3 * h * 64, device=dev).to(torch.bfloat16).requires_grad_(True)
         g = torch.randn(b, s, h * 64, device=dev).to(torch.bfloat16)
         flops = 4.0 * b * h * s * s * 64 * (0.5 if causal else 1.0)

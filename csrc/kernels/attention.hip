@@ -110,17 +110,17 @@ __device__ __forceinline__ void tile_dma_issue(const TileDma& d, const bf16* bas
     }
 }
 
-// Per-lane addressing of the fragment reads.
+// Per-lane addressing of the fragment reads (LDS byte offsets inside a tile).
 struct FragAddr {
-    uint32_t row_off[4];  // row-major A fragment of k-step ks: element offset inside the tile for row lane % 32 (+ 32 per row tile)
-    uint32_t tr[2][2];    // transposed A fragment: LDS byte offset inside the tile for [column tile dt][4-row block blk]
+    uint32_t row[4];    // row-major A fragment of k-step ks, row lane % 32 (+ 4096 per 32-row tile)
+    uint32_t tr[2][2];  // transposed A fragment: [column tile dt][4-row block blk] (+ 2048 per 16 rows)
 };
 
 __device__ __forceinline__ FragAddr frag_addr_setup(int lane) {
     FragAddr f;
     const int hi = lane >> 5, lq = lane & 31, l16 = lane & 15, half = (lane >> 4) & 1, piece = l16 & 3;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) f.row_off[ks] = lq * AT_D + (((2 * ks + hi) ^ at_swz(lq)) << 3);
+    for (int ks = 0; ks < 4; ++ks) f.row[ks] = lq * 128 + (((2 * ks + hi) ^ at_swz(lq)) << 4);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -132,37 +132,48 @@ __device__ __forceinline__ FragAddr frag_addr_setup(int lane) {
     return f;
 }
 
-// A[i][k] = tile[32 rt + i][16 ks + k]: rows of the tile as the 32 x 16 A operand
-__device__ __forceinline__ bf16x8 frag_rows(const bf16* tile, const FragAddr& f, int rt, int ks) {
-    return *reinterpret_cast<const bf16x8*>(tile + rt * (32 * AT_D) + f.row_off[ks]);
-}
+// Every LDS read of a kernel that has LDS-DMA in flight is inline assembly: the compiler cannot tell an ordinary LDS
+// load from the pending DMA writes and would drain the whole DMA queue (vmcnt(0)) in front of it, which takes away
+// the two tiles of prefetch.  Completion is therefore awaited by hand: LDS reads return in order, so a counted
+// lgkmcnt(N) releases all but the youngest N; the scheduling fence keeps the consumers behind the wait.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-// The eight transposed A fragments of one column tile dt: A[i][k] = tile[row(k)][32 dt + i] for the 16-row steps
-// (rt, j) of the tile, where row(k) follows the accumulator row order of the 32x32 MFMA (so packed accumulators are
-// the matching B operands).  Inline assembly: through the builtin the compiler cannot tell these reads from the
-// pending LDS-DMA writes and drains the whole DMA queue in front of them; their completion is awaited by hand.
-struct TrFrags {
-    s16x4 lo[2][2], hi[2][2];
-};
-
-__device__ __forceinline__ void frag_tr_issue(TrFrags& v, uint32_t tile_lds, const FragAddr& f, int dt) {
-    const uint32_t a0 = tile_lds + f.tr[dt][0], a1 = tile_lds + f.tr[dt][1];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v.lo[rt][j]) : "v"(a0), "n"((32 * rt + 16 * j) * 128) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v.hi[rt][j]) : "v"(a1), "n"((32 * rt + 16 * j) * 128) : "memory");
-        }
-}
-
-__device__ __forceinline__ void frag_tr_wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ bf16x8 frag_tr_get(const TrFrags& v, int rt, int j) {
-    const s16x8 r = {v.lo[rt][j][0], v.lo[rt][j][1], v.lo[rt][j][2], v.lo[rt][j][3], v.hi[rt][j][0], v.hi[rt][j][1], v.hi[rt][j][2], v.hi[rt][j][3]};
+// A[i][k] = tile[32 rt + i][16 ks + k], ks = 0..3: rows of the tile as four 32 x 16 A operands (4 reads)
+struct RowFrags {
+    u32x4 v[4];
+};
+__device__ __forceinline__ void frag_rows_issue(RowFrags& f, uint32_t tile_lds, const FragAddr& fa, int rt) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v[ks]) : "v"(tile_lds + fa.row[ks]), "n"(4096 * rt) : "memory");
+}
+__device__ __forceinline__ bf16x8 frag_rows_get(const RowFrags& f, int ks) { return __builtin_bit_cast(bf16x8, f.v[ks]); }
+
+// four consecutive floats of a per-row vector in LDS (the same address in every lane of a half wave: a broadcast)
+__device__ __forceinline__ void lds_read_f32x4(f32x4& v, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
+
+// Transposed A fragments of column tile dt for the two 16-row steps j of row tile rt (4 reads):
+// A[i][k] = tile[32 rt + 16 j + row(k)][32 dt + i], where row(k) follows the accumulator row order of the 32x32
+// MFMA, so that registers 8 j .. 8 j + 7 of a packed accumulator tile are the matching B operand.
+struct TrFrags {
+    s16x4 lo[2], hi[2];
+};
+__device__ __forceinline__ void frag_tr_issue(TrFrags& v, uint32_t tile_lds, const FragAddr& fa, int dt, int rt) {
+    const uint32_t a0 = tile_lds + fa.tr[dt][0], a1 = tile_lds + fa.tr[dt][1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v.lo[j]) : "v"(a0), "n"((32 * rt + 16 * j) * 128) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v.hi[j]) : "v"(a1), "n"((32 * rt + 16 * j) * 128) : "memory");
+    }
+}
+__device__ __forceinline__ bf16x8 frag_tr_get(const TrFrags& v, int j) {
+    const s16x8 r = {v.lo[j][0], v.lo[j][1], v.lo[j][2], v.lo[j][3], v.hi[j][0], v.hi[j][1], v.hi[j][2], v.hi[j][3]};
     return __builtin_bit_cast(bf16x8, r);
 }
 
@@ -254,35 +265,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     float lsum = 0.f;  // this lane's share (32 of every 64 keys) of the query's row sum
     float nm = 0.f;    // minus the running maximum, in log2 units
     const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;  // last key this lane's query attends to
-    const uint32_t sv_lds = lds_addr(&sVb[0][0]);
+    const uint32_t sk_lds = lds_addr(&sKb[0][0]), sv_lds = lds_addr(&sVb[0][0]);
 
     int buf = 0;
-    for (int t = 0; t < nt; ++t) {
-        const int k0 = t * AT_T;
-        // this wave's pieces of tile t have landed (those of tile t + 1 may still be in flight); after the barrier
-        // everybody's have, and nobody reads tile t - 1 any more: its buffer takes tile t + 2
+    // Start of tile t: this wave's pieces of the tile have landed (those of tile t + 1 may still be in flight); after
+    // the barrier everybody's have, and nobody reads tile t - 1 any more: its buffer takes tile t + 2.
+    auto next_tile = [&](int t) {
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 2 < nt) {
             const int nb = buf == 0 ? AT_RING - 1 : buf - 1;
-            tile_dma_issue(dma, kbase, srow, k0 + 2 * AT_T, p.S - 1, sKb[nb], wave);
-            tile_dma_issue(dma, vbase, srow, k0 + 2 * AT_T, p.S - 1, sVb[nb], wave);
+            tile_dma_issue(dma, kbase, srow, (t + 2) * AT_T, p.S - 1, sKb[nb], wave);
+            tile_dma_issue(dma, vbase, srow, (t + 2) * AT_T, p.S - 1, sVb[nb], wave);
         }
         const int cur = buf;
         buf = buf == AT_RING - 1 ? 0 : buf + 1;
-        if (t >= wave_nt) continue;
-        const bf16* sK = sKb[cur];
+        return cur;
+    };
+    for (int t = 0; t < wave_nt; ++t) {
+        const int k0 = t * AT_T;
+        const int cur = next_tile(t);
+        const uint32_t sk_tile = sk_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), sv_tile = sv_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2);
         const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T - 1 > qw0);
         f32x16 acc[2];
+        TrFrags vf[2][2];  // [column tile][key tile]
         // scores of the tile -> probabilities relative to the running maximum, in place; returns the lane's partial row sum
         auto score_tile = [&](const bool careful) {
+            RowFrags kf[2];
+            frag_rows_issue(kf[0], sk_tile, fa, 0);
+            frag_rows_issue(kf[1], sk_tile, fa, 1);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
+                if (kt == 0) lds_wait<4>();
+                else lds_wait<0>();
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[kt][e] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sK, fa, kt, ks), qf[ks], acc[kt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf[kt], ks), qf[ks], acc[kt], 0, 0, 0);
             }
+            // V^T fragments of the first column tile: in flight while the scores go through the vector ALU
+            frag_tr_issue(vf[0][0], sv_tile, fa, 0, 0);
+            frag_tr_issue(vf[0][1], sv_tile, fa, 0, 1);
             if (masked) {
                 const int rel = key_limit - k0 - 4 * hi;  // last valid key offset inside the tile, minus this half's share
 #pragma unroll
@@ -334,17 +357,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int j = 0; j < 2; ++j) pb[kt][j] = pack_half(acc[kt], j);
+        frag_tr_issue(vf[1][0], sv_tile, fa, 1, 0);
+        frag_tr_issue(vf[1][1], sv_tile, fa, 1, 1);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            TrFrags vf;
-            frag_tr_issue(vf, sv_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
-            frag_tr_wait();
+            if (dt == 0) lds_wait<8>();
+            else lds_wait<0>();
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf, kt, j), pb[kt][j], o[dt], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf[dt][kt], j), pb[kt][j], o[dt], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    for (int t = wave_nt; t < nt; ++t) next_tile(t);  // tiles only the later waves of the workgroup need
     // every wave is done with the K / V tiles: the first buffers become the staging area of the output rows
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     const float lt = other_half_sum(lsum);
@@ -412,35 +438,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = 0.f;
     const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;
-    const uint32_t sk_lds = lds_addr(&sKb[0][0]);
+    const uint32_t sk_lds = lds_addr(&sKb[0][0]), sv_lds = lds_addr(&sVb[0][0]);
 
     int buf = 0;
-    for (int t = 0; t < nt; ++t) {
-        const int k0 = t * AT_T;
+    auto next_tile = [&](int t) {  // see attn_fwd_kernel
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 2 < nt) {
             const int nb = buf == 0 ? AT_RING - 1 : buf - 1;
-            tile_dma_issue(dma, kbase, srow, k0 + 2 * AT_T, p.S - 1, sKb[nb], wave);
-            tile_dma_issue(dma, vbase, srow, k0 + 2 * AT_T, p.S - 1, sVb[nb], wave);
+            tile_dma_issue(dma, kbase, srow, (t + 2) * AT_T, p.S - 1, sKb[nb], wave);
+            tile_dma_issue(dma, vbase, srow, (t + 2) * AT_T, p.S - 1, sVb[nb], wave);
         }
         const int cur = buf;
         buf = buf == AT_RING - 1 ? 0 : buf + 1;
-        if (t >= wave_nt) continue;
-        const bf16* sK = sKb[cur];
-        const bf16* sV = sVb[cur];
+        return cur;
+    };
+    for (int t = 0; t < wave_nt; ++t) {
+        const int k0 = t * AT_T;
+        const int cur = next_tile(t);
+        const uint32_t sk_tile = sk_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), sv_tile = sv_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2);
         const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T - 1 > qw0);
         f32x16 s[2], dp[2];
+        {
+            RowFrags kf[2], vf[2];
+            frag_rows_issue(kf[0], sk_tile, fa, 0);
+            frag_rows_issue(vf[0], sv_tile, fa, 0);
+            frag_rows_issue(kf[1], sk_tile, fa, 1);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+            for (int kt = 0; kt < 2; ++kt) {
+                if (kt == 0) lds_wait<8>();
+                else lds_wait<4>();
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+                for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sK, fa, kt, ks), qf[ks], s[kt], 0, 0, 0);
-                dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sV, fa, kt, ks), dof[ks], ks == 0 ? ndelta : dp[kt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf[kt], ks), qf[ks], s[kt], 0, 0, 0);
+                if (kt == 0) {
+                    lds_wait<4>();
+                    frag_rows_issue(vf[1], sv_tile, fa, 1);
+                } else {
+                    lds_wait<0>();
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(vf[kt], ks), dof[ks], ks == 0 ? ndelta : dp[kt], 0, 0, 0);
             }
         }
+        TrFrags kt_f[2][2];  // K^T fragments [column tile][key tile]: the first column tile is in flight during the vector-ALU work
+        frag_tr_issue(kt_f[0][0], sk_tile, fa, 0, 0);
+        frag_tr_issue(kt_f[0][1], sk_tile, fa, 0, 1);
         if (masked) {
             const int rel = key_limit - k0 - 4 * hi;
 #pragma unroll
@@ -457,17 +502,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int j = 0; j < 2; ++j) dsb[kt][j] = pack_half(s[kt], j);
+        frag_tr_issue(kt_f[1][0], sk_tile, fa, 1, 0);
+        frag_tr_issue(kt_f[1][1], sk_tile, fa, 1, 1);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            TrFrags kf;
-            frag_tr_issue(kf, sk_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
-            frag_tr_wait();
+            if (dt == 0) lds_wait<8>();
+            else lds_wait<0>();
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(kf, kt, j), dsb[kt][j], dq[dt], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(kt_f[dt][kt], j), dsb[kt][j], dq[dt], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    for (int t = wave_nt; t < nt; ++t) next_tile(t);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     bf16* drow0 = p.dqkv + qkv_off(p, b, min(qw0, p.S - 1), 0, h);
     store_rows32(&sKb[0][0] + wave * (32 * AT_D), dq, p.scale, lane, p.S - qw0, [&](int row) { return drow0 + static_cast<size_t>(row) * srow; });
@@ -520,82 +568,87 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) dk[0][e] = dk[1][e] = dv[0][e] = dv[1][e] = 0.f;
-    const uint32_t sq_lds = lds_addr(&sQb[0][0]), sdo_lds = lds_addr(&sDOb[0][0]);
+    const uint32_t sq_lds = lds_addr(&sQb[0][0]), sdo_lds = lds_addr(&sDOb[0][0]), srow_lds = lds_addr(&sRow[0][0][0]);
 
     int buf = 0;
-    for (int t = t0; t < nt; ++t) {
-        const int q0 = t * AT_T;
+    auto next_tile = [&](int t) {  // see attn_fwd_kernel; five DMA instructions per wave and tile here
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 2 < nt) issue(t + 2, buf == 0 ? AT_RING - 1 : buf - 1);
         const int cur = buf;
         buf = buf == AT_RING - 1 ? 0 : buf + 1;
-        if (t < wave_t0) continue;
-        const bf16* sQ = sQb[cur];
-        const bf16* sDO = sDOb[cur];
+        return cur;
+    };
+    for (int t = t0; t < min(wave_t0, nt); ++t) next_tile(t);  // query tiles only the earlier waves of the workgroup need
+    for (int t = max(t0, wave_t0); t < nt; ++t) {
+        const int q0 = t * AT_T;
+        const int cur = next_tile(t);
+        const uint32_t sq_tile = sq_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), sdo_tile = sdo_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2);
+        const uint32_t row_tile = srow_lds + static_cast<uint32_t>(cur) * (4 * AT_T * 4) + 16 * hi;  // this half's first float4
         // per-element masking only where it can matter: queries beyond S, the causal diagonal (wave-uniform)
         const bool masked = (q0 + AT_T > p.S) || (p.causal && q0 < kw0 + 31);
-        f32x16 s[2], dp[2];
+        const int lo = (p.causal ? key : 0) - q0 - 4 * hi, up = p.S - 1 - q0 - 4 * hi;  // valid query offsets: [lo, up]
+        // the tile is processed as two halves of 32 queries: accumulator register r of a half is its query
+        // (r & 3) + 8 (r >> 2) + 4 hi, so a lane needs four float4 of the half's lse / -delta rows
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            // accumulator register r of this lane is query 32 qt + (r & 3) + 8 (r >> 2) + 4 hi of the tile
+            f32x16 s, dp;
+            f32x4 l2[4];
+            {
+                RowFrags qf, dof;
+                f32x4 nd[4];
+                frag_rows_issue(qf, sq_tile, fa, qt);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 nd = *reinterpret_cast<const f32x4*>(&sRow[cur][1][32 * qt + 8 * r4 + 4 * hi]);
+                for (int r4 = 0; r4 < 4; ++r4) lds_read_f32x4(nd[r4], row_tile + AT_T * 4 + (32 * qt + 8 * r4) * 4);
+                frag_rows_issue(dof, sdo_tile, fa, qt);
+                lds_wait<8>();
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dp[qt][4 * r4 + e] = nd[e];
-                    s[qt][4 * r4 + e] = 0.f;
-                }
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(qf, ks), kf[ks], s, 0, 0, 0);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) lds_read_f32x4(l2[r4], row_tile + (32 * qt + 8 * r4) * 4);
+                lds_wait<4>();
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dp[e] = nd[e >> 2][e & 3];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(dof, ks), vf[ks], dp, 0, 0, 0);
             }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sQ, fa, qt, ks), kf[ks], s[qt], 0, 0, 0);
-                dp[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(sDO, fa, qt, ks), vf[ks], dp[qt], 0, 0, 0);
-            }
-        }
-        if (masked) {
-            const int lo = (p.causal ? key : 0) - q0 - 4 * hi, up = p.S - 1 - q0 - 4 * hi;  // valid query offsets: [lo, up]
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            TrFrags dot[2], qt_f[2];  // dO^T / Q^T fragments per column tile
+            frag_tr_issue(dot[0], sdo_tile, fa, 0, qt);
+            frag_tr_issue(qt_f[0], sq_tile, fa, 0, qt);
+            lds_wait<8>();  // lse
+            if (masked) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int qo = 32 * qt + (r & 3) + 8 * (r >> 2);
-                    s[qt][r] = (qo >= lo && qo <= up) ? s[qt][r] : AT_NEG;
-                }
-        }
-        bf16x8 pb[2][2], dsb[2][2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 l2 = *reinterpret_cast<const f32x4*>(&sRow[cur][0][32 * qt + 8 * r4 + 4 * hi]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = fast_exp2(fmaf(s[qt][4 * r4 + e], p.scale_log2, -l2[e]));
-                    s[qt][4 * r4 + e] = pv;
-                    dp[qt][4 * r4 + e] *= pv;
+                    s[r] = (qo >= lo && qo <= up) ? s[r] : AT_NEG;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = fast_exp2(fmaf(s[r], p.scale_log2, -l2[r >> 2][r & 3]));
+                dp[r] *= s[r];
+            }
+            bf16x8 pb[2], dsb[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                pb[qt][j] = pack_half(s[qt], j);
-                dsb[qt][j] = pack_half(dp[qt], j);
+                pb[j] = pack_half(s, j);
+                dsb[j] = pack_half(dp, j);
             }
-        }
+            frag_tr_issue(dot[1], sdo_tile, fa, 1, qt);
+            frag_tr_issue(qt_f[1], sq_tile, fa, 1, qt);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            TrFrags dof, qf;
-            frag_tr_issue(dof, sdo_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
-            frag_tr_issue(qf, sq_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), fa, dt);
-            frag_tr_wait();
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int dt = 0; dt < 2; ++dt) {
+                if (dt == 0) lds_wait<8>();
+                else lds_wait<0>();
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(dof, qt, j), pb[qt][j], dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(qf, qt, j), dsb[qt][j], dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(dot[dt], j), pb[j], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(qt_f[dt], j), dsb[j], dk[dt], 0, 0, 0);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
