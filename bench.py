@@ -60,7 +60,7 @@ def _claim_stdout():
     return real
 
 
-DEFAULT_BATCH = {"resnet50": 2048, "vit_b_16": 1024, "gpt2_medium": 32}
+DEFAULT_BATCH = {"resnet50": 2048, "vit_b_16": 1024, "gpt2_medium": 128}
 
 
 def main():

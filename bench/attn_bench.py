@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -16,9 +17,13 @@ SHAPES = [("gpt2-medium b32", 32, 1024, 16, True), ("vit-b/16 b256", 256, 197, 1
 
 
 def _time(run, iters=20):
-    for _ in range(3):
-        run()
+    # warm up for at least 30 ms: the first launches of a process run at a lower clock
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.03:
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

@@ -287,43 +287,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
         const int cur = next_tile(t);
         const uint32_t sk_tile = sk_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), sv_tile = sv_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2);
         const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T - 1 > qw0);
-        f32x16 acc[2];
-        TrFrags vf[2][2];  // [column tile][key tile]
-        // scores of the tile -> probabilities relative to the running maximum, in place; returns the lane's partial row sum
-        auto score_tile = [&](const bool careful) {
-            RowFrags kf[2];
-            frag_rows_issue(kf[0], sk_tile, fa, 0);
-            frag_rows_issue(kf[1], sk_tile, fa, 1);
+        const int rel = key_limit - k0 - 4 * hi;  // last valid key offset inside the tile, minus this half wave's share
+        // The tile is handled as two halves of 32 keys, software-pipelined so that the matrix pipe always has work
+        // queued while the vector ALU turns scores into probabilities:
+        //   S(0) S(1) | softmax(0) | PV(0) | softmax(1) | PV(1)
+        f32x16 acc0, acc1;
+        auto scores = [&](f32x16& acc, const RowFrags& kf) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                if (kt == 0) lds_wait<4>();
-                else lds_wait<0>();
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[kt][e] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf[kt], ks), qf[ks], acc[kt], 0, 0, 0);
-            }
-            // V^T fragments of the first column tile: in flight while the scores go through the vector ALU
-            frag_tr_issue(vf[0][0], sv_tile, fa, 0, 0);
-            frag_tr_issue(vf[0][1], sv_tile, fa, 0, 1);
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf, ks), qf[ks], acc, 0, 0, 0);
+        };
+        // scores of a half (keys k0 + koff ...) -> probabilities relative to the running maximum, in place; returns the
+        // lane's partial row sum
+        auto probs = [&](f32x16& acc, const int koff, const bool careful, const bool first) {
             if (masked) {
-                const int rel = key_limit - k0 - 4 * hi;  // last valid key offset inside the tile, minus this half's share
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= rel ? acc[kt][r] : AT_NEG;
+                for (int r = 0; r < 16; ++r) acc[r] = (koff + (r & 3) + 8 * (r >> 2)) <= rel ? acc[r] : AT_NEG;
             }
             if (careful) {
                 float mx = AT_NEG;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[kt][r]);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[r]);
                 mx = other_half_max(mx) * p.scale_log2;
-                // first tile: the maximum becomes the reference whatever its sign; later: only ever raised
+                // very first half: the maximum becomes the reference whatever its sign; later: only ever raised
                 const float cand = mx < -1.0e29f ? -nm : mx;
-                const float m_new = t == 0 ? cand : fmaxf(cand, -nm);
-                if (t != 0) {
+                const float m_new = first ? cand : fmaxf(cand, -nm);
+                if (!first) {
                     const float alpha = fast_exp2(-nm - m_new);
                     lsum *= alpha;
 #pragma unroll
@@ -336,37 +326,56 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
             }
             float sum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[kt][r] = fast_exp2(fmaf(acc[kt][r], p.scale_log2, nm));  // masked scores are -1e30: 2^-huge = 0
-                    sum += acc[kt][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = fast_exp2(fmaf(acc[r], p.scale_log2, nm));  // masked scores are -1e30: 2^-huge = 0
+                sum += acc[r];
+            }
             return sum;
         };
-        float ls;
-        if (t == 0) {
-            ls = score_tile(true);
-        } else {
-            ls = score_tile(false);
-            if (__builtin_expect(__any(!(ls <= 1073741824.f)), 0)) ls = score_tile(true);
+        // common path: no maximum; a half whose partial row sum is beyond 2^30 (or not a number) is recomputed carefully
+        auto softmax_half = [&](f32x16& acc, const int kt) {
+            const bool first = t == 0 && kt == 0;
+            float ls = probs(acc, 32 * kt, first, first);
+            if (!first && __builtin_expect(__any(!(ls <= 1073741824.f)), 0)) {
+                RowFrags kf;
+                frag_rows_issue(kf, sk_tile, fa, kt);
+                lds_wait<0>();
+                scores(acc, kf);
+                ls = probs(acc, 32 * kt, true, false);
+            }
+            lsum += ls;
+        };
+        TrFrags vf0[2], vf1[2];  // V^T fragments of the two key halves, per column tile
+        {
+            RowFrags kf0, kf1;
+            frag_rows_issue(kf0, sk_tile, fa, 0);
+            frag_rows_issue(kf1, sk_tile, fa, 1);
+            lds_wait<4>();
+            scores(acc0, kf0);
+            lds_wait<0>();
+            scores(acc1, kf1);
         }
-        lsum += ls;
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) pb[kt][j] = pack_half(acc[kt], j);
-        frag_tr_issue(vf[1][0], sv_tile, fa, 1, 0);
-        frag_tr_issue(vf[1][1], sv_tile, fa, 1, 1);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            if (dt == 0) lds_wait<8>();
-            else lds_wait<0>();
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf[dt][kt], j), pb[kt][j], o[dt], 0, 0, 0);
+        frag_tr_issue(vf0[0], sv_tile, fa, 0, 0);
+        frag_tr_issue(vf0[1], sv_tile, fa, 1, 0);
+        softmax_half(acc0, 0);
+        {
+            const bf16x8 pb0 = pack_half(acc0, 0), pb1 = pack_half(acc0, 1);
+            frag_tr_issue(vf1[0], sv_tile, fa, 0, 1);
+            frag_tr_issue(vf1[1], sv_tile, fa, 1, 1);
+            lds_wait<8>();
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf0[0], 0), pb0, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf0[1], 0), pb0, o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf0[0], 1), pb1, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf0[1], 1), pb1, o[1], 0, 0, 0);
+        }
+        softmax_half(acc1, 1);
+        {
+            const bf16x8 pb0 = pack_half(acc1, 0), pb1 = pack_half(acc1, 1);
+            lds_wait<0>();
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf1[0], 0), pb0, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf1[1], 0), pb0, o[1], 0, 0, 0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf1[0], 1), pb1, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(vf1[1], 1), pb1, o[1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
