@@ -31,8 +31,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=0,
-                    help="per-GPU batch; 0 = the model's default, sized for 288 GB of HBM (ResNet-50 2048: 81 GiB, "
-                         "ViT-B/16 1024: 60 GiB, GPT-2 medium 32: 37 GiB - its logits tensor is near the 2^31-element limit)")
+                    help="per-GPU batch; 0 = the model's default, sized for 288 GB of HBM (ResNet-50 2048: 77 GiB, "
+                         "ViT-B/16 1024: 60 GiB, GPT-2 medium 128: 107 GiB)")
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=1024)
@@ -248,7 +248,8 @@ def main():
     shutdown(env)
 
 
-STOCK_PER_GPU = {"resnet50": 6888.2, "vit_b_16": 4073.8, "gpt2_medium": 194240.0}
+# stock PyTorch-ROCm 2.10 on one MI355X at the same per-GPU batch (bench/stock_baseline.py; MIOpen find mode for ResNet-50)
+STOCK_PER_GPU = {"resnet50": 6888.2, "vit_b_16": 4073.8, "gpt2_medium": 217173.9}
 
 
 def collect_extras(extras, args, env, model, raw, step, sync, zero_grad, elapsed, on_gpu, dev):

@@ -32,7 +32,7 @@ def main():
         del yf
         g = torch.randn(nb, cout, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         cols = []
-        for fused in (0, 1):
+        for fused in (0, 2):
             hip.FUSE_BN_INTO_1X1 = fused
             tf = tb = 0.0
             iters = 8

@@ -7,8 +7,14 @@ convolution), its initialisation and - importantly - its parameter and buffer na
 ``state_dict`` saved by this framework loads into a stock torchvision ResNet and back.
 
 The forward pass is written in terms of *raw convolution outputs plus pending
-normalisation*: BatchNorm+ReLU is never a stand-alone layer here, it is either folded into
-the next convolution's operand load or into the block-tail kernel (see ``ops``).
+normalisation*: a convolution returns its output together with the batch statistics its
+kernel epilogue gathered, and the consumer decides how the normalisation is applied.  On
+GPU (``ops.hip``): in front of a 1x1 convolution with at most 128 input channels,
+BatchNorm+ReLU is applied to the operand tiles inside the GEMM and weight-gradient kernels
+and the normalised activation is never written; in front of the other convolutions it is
+one streaming pass (read ``y``, write ``relu(bn(y))``) at HBM rate, because there the
+in-kernel transform was measured to cost more than the pass it saves; block tails fuse
+BatchNorm, the shortcut add and ReLU into one pass, the stem adds the max-pool.
 """
 
 from __future__ import annotations

@@ -57,7 +57,9 @@ def bn_act(y, stats, bn, relu: bool = True):
 
 
 def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
-    """conv(relu(bn(y_prev))) with the normalisation applied on the way into the convolution."""
+    """conv(relu(bn(y_prev))) from a raw convolution output and its batch statistics.  On GPU the normalisation is
+    applied inside the convolution's kernels for 1x1 consumers with at most 128 input channels (no normalised
+    activation is written) and as one streaming pass in front of the convolution otherwise (``ops.hip.FUSE_BN_INTO_1X1``)."""
     if y_prev.is_cuda:
         return _hip().bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride, padding)
     return _ref.bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride, padding)

@@ -1037,6 +1037,11 @@ def bn_act(y, stats, bn, relu: bool = True):
     return _BnAct.apply(y, stats, bn.weight, bn.bias, bn, relu, None)
 
 
+# 0: BatchNorm + ReLU always as a pass of its own; 1: applied inside the 1x1 consumer's kernels where that is measured
+# to be no slower (consumers with at most 128 input channels: their GEMMs are bound by the output stores, so the
+# transform of the operand tile in LDS hides; with 256+ input channels the launches are bound by LDS / MFMA and
+# the transform costs more than the saved pass - bench/bn_fuse_bench.py); 2: wherever the kernels allow (saves the
+# most memory).
 FUSE_BN_INTO_1X1 = int(_os.environ.get("PDT_FUSE_BN_1X1", "1"))
 
 
@@ -1049,6 +1054,8 @@ def _can_fuse_bn_into_conv(y_prev, bn, weight, stride: int, padding: int) -> boo
         return False
     n, c, r, s = weight.shape
     if (r, s) != (1, 1) or stride != 1 or padding != 0 or not bn.training or c % 64 or n % 64 or c > 2048:
+        return False
+    if FUSE_BN_INTO_1X1 == 1 and c > 128:
         return False
     nb, _, h, w = y_prev.shape
     M = nb * h * w

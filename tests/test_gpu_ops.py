@@ -737,7 +737,7 @@ def test_bn_relu_fused_into_the_1x1_convolution_kernels(hip, monkeypatch, case):
     real_launch = hip._launch_gather_gemm
     monkeypatch.setattr(hip, "_launch_gather_gemm", lambda *a, **kw: (launched.append(kw.get("xf") is not None), real_launch(*a, **kw))[1])
     for fused in (True, False):
-        monkeypatch.setattr(hip, "FUSE_BN_INTO_1X1", 1 if fused else 0)
+        monkeypatch.setattr(hip, "FUSE_BN_INTO_1X1", 2 if fused else 0)  # 2: wherever the kernels allow
         bn = nn.BatchNorm2d(cin).to(dev)
         with torch.no_grad():
             bn.weight.copy_(gamma)
