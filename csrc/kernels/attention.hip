@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 // delta[q] = sum_d dO[q][d] O[q][d] is formed from the dO fragments the wave holds anyway and written (negated) for
 // the dK/dV kernel, which runs after this one.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(1024))) bf16 sKb[AT_RING][AT_TILE];
     __shared__ __attribute__((aligned(1024))) bf16 sVb[AT_RING][AT_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,9 +443,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
             tile_dma_issue(dma, kbase, srow, t * AT_T, p.S - 1, sKb[t], wave);
             tile_dma_issue(dma, vbase, srow, t * AT_T, p.S - 1, sVb[t], wave);
         }
-    f32x16 dq[2];
+    f32x16 dq[2], zero16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = 0.f;
+    for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = zero16[e] = 0.f;
     const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;
     const uint32_t sk_lds = lds_addr(&sKb[0][0]), sv_lds = lds_addr(&sVb[0][0]);
 
@@ -467,62 +467,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         const int cur = next_tile(t);
         const uint32_t sk_tile = sk_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2), sv_tile = sv_lds + static_cast<uint32_t>(cur) * (AT_TILE * 2);
         const bool masked = (k0 + AT_T > p.S) || (p.causal && k0 + AT_T - 1 > qw0);
-        f32x16 s[2], dp[2];
-        {
-            RowFrags kf[2], vf[2];
-            frag_rows_issue(kf[0], sk_tile, fa, 0);
-            frag_rows_issue(vf[0], sv_tile, fa, 0);
-            frag_rows_issue(kf[1], sk_tile, fa, 1);
+        const int rel = key_limit - k0 - 4 * hi;
+        // two halves of 32 keys, one after the other: S^T and dP^T of a half, its vector-ALU work, its share of dQ^T
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                if (kt == 0) lds_wait<8>();
-                else lds_wait<4>();
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 s, dp;
+            {
+                RowFrags kf, vf;
+                frag_rows_issue(kf, sk_tile, fa, kt);
+                frag_rows_issue(vf, sv_tile, fa, kt);
+                lds_wait<4>();
 #pragma unroll
-                for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf, ks), qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+                lds_wait<0>();
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf[kt], ks), qf[ks], s[kt], 0, 0, 0);
-                if (kt == 0) {
-                    lds_wait<4>();
-                    frag_rows_issue(vf[1], sv_tile, fa, 1);
-                } else {
-                    lds_wait<0>();
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(vf[kt], ks), dof[ks], ks == 0 ? ndelta : dp[kt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(vf, ks), dof[ks], ks == 0 ? ndelta : dp, 0, 0, 0);
             }
+            TrFrags kt_f[2];  // K^T fragments per column tile, in flight during the vector-ALU work
+            frag_tr_issue(kt_f[0], sk_tile, fa, 0, kt);
+            frag_tr_issue(kt_f[1], sk_tile, fa, 1, kt);
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= rel ? s[r] : AT_NEG;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], p.scale_log2, nl)) * dp[r];
+            const bf16x8 ds0 = pack_half(s, 0), ds1 = pack_half(s, 1);
+            lds_wait<0>();
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(kt_f[dt], 0), ds0, dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(kt_f[dt], 1), ds1, dq[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        TrFrags kt_f[2][2];  // K^T fragments [column tile][key tile]: the first column tile is in flight during the vector-ALU work
-        frag_tr_issue(kt_f[0][0], sk_tile, fa, 0, 0);
-        frag_tr_issue(kt_f[0][1], sk_tile, fa, 0, 1);
-        if (masked) {
-            const int rel = key_limit - k0 - 4 * hi;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = (32 * kt + (r & 3) + 8 * (r >> 2)) <= rel ? s[kt][r] : AT_NEG;
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = fast_exp2(fmaf(s[kt][r], p.scale_log2, nl)) * dp[kt][r];
-        bf16x8 dsb[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dsb[kt][j] = pack_half(s[kt], j);
-        frag_tr_issue(kt_f[1][0], sk_tile, fa, 1, 0);
-        frag_tr_issue(kt_f[1][1], sk_tile, fa, 1, 1);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            if (dt == 0) lds_wait<8>();
-            else lds_wait<0>();
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_get(kt_f[dt][kt], j), dsb[kt][j], dq[dt], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
     for (int t = wave_nt; t < nt; ++t) next_tile(t);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
