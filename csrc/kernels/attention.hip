@@ -443,9 +443,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnArgs p) {
             tile_dma_issue(dma, kbase, srow, t * AT_T, p.S - 1, sKb[t], wave);
             tile_dma_issue(dma, vbase, srow, t * AT_T, p.S - 1, sVb[t], wave);
         }
-    f32x16 dq[2], zero16;
+    f32x16 dq[2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = zero16[e] = 0.f;
+    for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = 0.f;
     const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;
     const uint32_t sk_lds = lds_addr(&sKb[0][0]), sv_lds = lds_addr(&sVb[0][0]);
 
@@ -478,7 +478,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnArgs p) {
                 frag_rows_issue(vf, sv_tile, fa, kt);
                 lds_wait<4>();
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf, ks), qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(kf, ks), qf[ks], s, 0, 0, 0);
                 lds_wait<0>();
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(vf, ks), dof[ks], ks == 0 ? ndelta : dp, 0, 0, 0);
@@ -580,27 +582,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             f32x16 s, dp;
-            f32x4 l2[4];
             {
-                RowFrags qf, dof;
+                RowFrags qf;
                 f32x4 nd[4];
                 frag_rows_issue(qf, sq_tile, fa, qt);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) lds_read_f32x4(nd[r4], row_tile + AT_T * 4 + (32 * qt + 8 * r4) * 4);
-                frag_rows_issue(dof, sdo_tile, fa, qt);
-                lds_wait<8>();
+                lds_wait<4>();
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(qf, ks), kf[ks], s, 0, 0, 0);
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) lds_read_f32x4(l2[r4], row_tile + (32 * qt + 8 * r4) * 4);
-                lds_wait<4>();
+                RowFrags dof;
+                frag_rows_issue(dof, sdo_tile, fa, qt);
+                lds_wait<0>();
 #pragma unroll
                 for (int e = 0; e < 16; ++e) dp[e] = nd[e >> 2][e & 3];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_get(dof, ks), vf[ks], dp, 0, 0, 0);
             }
+            f32x4 l2[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) lds_read_f32x4(l2[r4], row_tile + (32 * qt + 8 * r4) * 4);
             TrFrags dot[2], qt_f[2];  // dO^T / Q^T fragments per column tile
             frag_tr_issue(dot[0], sdo_tile, fa, 0, qt);
             frag_tr_issue(qt_f[0], sq_tile, fa, 0, qt);
