@@ -5,57 +5,126 @@
 // Not exercised by the reference (its model is a CNN, /root/reference/src/main.py:49); they serve the
 // ViT-B/16 and GPT-2 data-parallel workloads.
 #include "common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm
 // ------------------------------------------------------------------------------------------------
+// Activations beyond 160 MB are streamed past the caches (NT): nothing that large survives until its consumer runs,
+// and ordinary stores of it evict what the next kernel could have reused.
+template <bool NT>
+__device__ __forceinline__ bf16x8 ln_ld8(const bf16* q) {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(q)) : *reinterpret_cast<const bf16x8*>(q);
+}
+template <bool NT>
+__device__ __forceinline__ void ln_st8(bf16* q, const bf16x8& v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(q));
+    else *reinterpret_cast<bf16x8*>(q) = v;
+}
+static inline bool ln_stream(int rows, int D) { return static_cast<long long>(rows) * D * 2 > (160ll << 20); }
+
+// Persistent waves walk rows row0, row0 + stride, ...: a row (up to 64 * 8 * MAXV columns) is read once and stays in
+// registers between the statistics and the output pass, the next row's loads are issued before the current row is
+// reduced (two rows in flight per wave), and - up to 1024 columns - a lane keeps its gamma / beta in registers.
+template <int MAXV, bool NT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16* __restrict__ y,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                            int rows, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const bf16* xr = x + static_cast<size_t>(row) * D;
+    constexpr bool KEEP = MAXV <= 2;
+    constexpr int NK = KEEP ? MAXV : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
-    float s1 = 0.f, s2 = 0.f;
-    for (int v = lane; v < nv; v += 64) {
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+    float gm[NK][8], bt[NK][8];
+    if (KEEP) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = bf16_to_f32(xv[e]);
-            s1 += f;
-            s2 += f * f;
+        for (int i = 0; i < NK; ++i) {
+            const int v = lane + 64 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gm[i][e] = v < nv ? gamma[v * 8 + e] : 0.f;
+                bt[i][e] = v < nv ? beta[v * 8 + e] : 0.f;
+            }
         }
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    const float mean = s1 / D;
-    const float rstd = rsqrtf(fmaxf(s2 / D - mean * mean, 0.f) + eps);
-    if (lane == 0) {
-        mean_out[row] = mean;
-        rstd_out[row] = rstd;
-    }
-    bf16* yr = y + static_cast<size_t>(row) * D;
-    for (int v = lane; v < nv; v += 64) {
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + v * 8);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
-        bf16x8 o;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_row = [&](bf16x8(&r)[MAXV], int row) {
+        const bf16* xr = x + static_cast<size_t>(row) * D;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float g = e < 4 ? g0[e] : g1[e - 4], b = e < 4 ? b0[e] : b1[e - 4];
-            o[e] = f32_to_bf16((bf16_to_f32(xv[e]) - mean) * rstd * g + b);
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            r[i] = v < nv ? ln_ld8<NT>(xr + v * 8) : zero8;
         }
-        *reinterpret_cast<bf16x8*>(yr + v * 8) = o;
+    };
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    bf16x8 cur[MAXV], nxt[MAXV];
+    load_row(cur, row);
+    const float inv_d = 1.f / D;
+    for (; row < rows; row += stride) {
+        const bool more = row + stride < rows;
+        if (more) load_row(nxt, row + stride);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf16_to_f32(cur[i][e]);  // lanes beyond the row hold zeros
+                s1 += f;
+                s2 += f * f;
+            }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const float mean = s1 * inv_d;
+        const float rstd = rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + eps);
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+        bf16* yr = y + static_cast<size_t>(row) * D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = KEEP ? gm[i][e] : gamma[v * 8 + e], bb = KEEP ? bt[i][e] : beta[v * 8 + e];
+                    o[e] = f32_to_bf16((bf16_to_f32(cur[i][e]) - mean) * rstd * g + bb);
+                }
+                ln_st8<NT>(yr + v * 8, o);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) cur[i] = nxt[i];
+        }
     }
 }
 
 PDT_API int pdt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                               int rows, int D, float eps, void* stream) {
-    if (rows <= 0 || D <= 0 || (D % 8) != 0) return -1;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(pdt_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16*>(x), gamma, beta, static_cast<bf16*>(y), mean, rstd, rows, D, eps);
+    if (rows <= 0 || D <= 0 || (D % 8) != 0 || D > 8 * 64 * 8) return -1;
+    const int maxv = (D / 8 + 63) / 64;
+    // Two workgroups of four persistent waves per CU: a wave's preload of gamma / beta (8 KB) is then small against the
+    // rows it walks; measured best for streamed and cache-resident tensors alike (bench/ln_bench.py).
+    const bool nt = ln_stream(rows, D);
+    const int want = pdt_cdiv(rows, 4), cap = 256 * 2;
+    const dim3 grid(want < cap ? want : cap);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PDT_LNF(V)                                                                                                                  \
+    do {                                                                                                                            \
+        if (nt) hipLaunchKernelGGL((layernorm_fwd_kernel<V, true>), grid, dim3(256), 0, s, static_cast<const bf16*>(x), gamma, beta, \
+                                   static_cast<bf16*>(y), mean, rstd, rows, D, eps);                                                \
+        else hipLaunchKernelGGL((layernorm_fwd_kernel<V, false>), grid, dim3(256), 0, s, static_cast<const bf16*>(x), gamma, beta,   \
+                                static_cast<bf16*>(y), mean, rstd, rows, D, eps);                                                   \
+    } while (0)
+    if (maxv <= 1) PDT_LNF(1);
+    else if (maxv <= 2) PDT_LNF(2);
+    else if (maxv <= 4) PDT_LNF(4);
+    else PDT_LNF(8);
+#undef PDT_LNF
     return pdt_launch_status();
 }
 
@@ -68,7 +137,7 @@ PDT_API int pdt_layernorm_fwd(const void* x, const float* gamma, const float* be
 // the reduction and the output pass (rows of up to 2048 columns), so each is read from memory once.
 // `addend` (optional) is a second gradient of the same input - the skip connection around the normalised
 // branch - added here instead of by a separate element-wise pass.
-template <int MAXV, int LN_BWD_WAVES>
+template <int MAXV, int LN_BWD_WAVES, bool NT>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const bf16* __restrict__ addend,
@@ -91,23 +160,46 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
             for (int e = 0; e < 8; ++e) gm[i][e] = v < nv ? gamma[v * 8 + e] : 0.f;
         }
     }
-    for (int row = blockIdx.x * LN_BWD_WAVES + wave; row < rows; row += gridDim.x * LN_BWD_WAVES) {
+    // KEEP: a row's dy, x and addend vectors stay in registers, and the next row's loads are issued before the current
+    // row is reduced, so two rows are in flight per wave.
+    bf16x8 dk[NK], xk[NK], ak[NK], dn[NK], xn[NK], an[NK];
+    float mu_n = 0.f, rs_n = 0.f;
+    auto load_row = [&](bf16x8(&d)[NK], bf16x8(&xx)[NK], bf16x8(&aa)[NK], float& mu_o, float& rs_o, int row) {
+        const bf16* dyr = dy + static_cast<size_t>(row) * D;
+        const bf16* xr = x + static_cast<size_t>(row) * D;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nv) {
+                d[i] = ln_ld8<NT>(dyr + v * 8);
+                xx[i] = ln_ld8<NT>(xr + v * 8);
+                if (addend != nullptr) aa[i] = ln_ld8<NT>(addend + static_cast<size_t>(row) * D + v * 8);
+            }
+        }
+        mu_o = mean[row];
+        rs_o = rstd[row];
+    };
+    const int row_first = blockIdx.x * LN_BWD_WAVES + wave, row_stride = gridDim.x * LN_BWD_WAVES;
+    if (KEEP && row_first < rows) load_row(dn, xn, an, mu_n, rs_n, row_first);
+    for (int row = row_first; row < rows; row += row_stride) {
         const bf16* dyr = dy + static_cast<size_t>(row) * D;
         const bf16* xr = x + static_cast<size_t>(row) * D;
         const bf16* ar = addend != nullptr ? addend + static_cast<size_t>(row) * D : nullptr;
-        bf16x8 dk[NK], xk[NK], ak[NK];
-        if (KEEP) {  // all of the row's loads in flight before the first use
+        float mu, rs;
+        if (KEEP) {
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
-                const int v = lane + 64 * i;
-                if (v < nv) {
-                    dk[i] = *reinterpret_cast<const bf16x8*>(dyr + v * 8);
-                    xk[i] = *reinterpret_cast<const bf16x8*>(xr + v * 8);
-                    if (ar != nullptr) ak[i] = *reinterpret_cast<const bf16x8*>(ar + v * 8);
-                }
+                dk[i] = dn[i];
+                xk[i] = xn[i];
+                ak[i] = an[i];
             }
+            mu = mu_n;
+            rs = rs_n;
+            if (row + row_stride < rows) load_row(dn, xn, an, mu_n, rs_n, row + row_stride);
+        } else {
+            mu = mean[row];
+            rs = rstd[row];
         }
-        const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -146,7 +238,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
                     if (ar != nullptr) r += bf16_to_f32(av[e]);
                     o[e] = f32_to_bf16(r);
                 }
-                *reinterpret_cast<bf16x8*>(dxr + v * 8) = o;
+                ln_st8<NT>(dxr + v * 8, o);
             }
         }
     }
@@ -224,7 +316,14 @@ PDT_API int pdt_layernorm_bwd(const void* dy, const void* x, const float* gamma,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16 *pdy = static_cast<const bf16*>(dy), *px = static_cast<const bf16*>(x), *pa = static_cast<const bf16*>(addend);
     bf16* pdx = static_cast<bf16*>(dx);
-#define PDT_LN(V, W) hipLaunchKernelGGL((layernorm_bwd_kernel<V, W>), dim3(grid), dim3(W * 64), 0, s, pdy, px, gamma, mean, rstd, pa, pdx, partial, rows, D)
+    const bool nt = ln_stream(rows, D);
+#define PDT_LN(V, W)                                                                                                                     \
+    do {                                                                                                                                 \
+        if (nt) hipLaunchKernelGGL((layernorm_bwd_kernel<V, W, true>), dim3(grid), dim3(W * 64), 0, s, pdy, px, gamma, mean, rstd, pa, pdx, \
+                                   partial, rows, D);                                                                                    \
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<V, W, false>), dim3(grid), dim3(W * 64), 0, s, pdy, px, gamma, mean, rstd, pa, pdx,  \
+                                partial, rows, D);                                                                                       \
+    } while (0)
     if (maxv <= 1) PDT_LN(1, 8);
     else if (maxv <= 2) PDT_LN(2, 8);
     else if (maxv <= 4) PDT_LN(4, 4);
