@@ -108,6 +108,33 @@ def test_attention_forward_backward(ht, b, s, h, causal):
     assert _rel(dq, rq) < 2e-2
 
 
+@pytest.mark.parametrize("b,s,h,causal,amp", [(2, 1, 2, True, 1.0), (2, 77, 3, True, 1.0), (1, 1000, 4, False, 1.0), (2, 300, 2, True, 6.0),
+                                              (2, 300, 2, False, 12.0), (1, 520, 2, True, 30.0)])
+def test_attention_ragged_lengths_and_scores_hundreds_of_octaves_apart(ht, b, s, h, causal, amp):
+    """Sequence ends inside a tile / inside a 128-row block, a single key, and inputs scaled so that scores reach
+    +-1000: the forward kernel takes no running maximum on its common path, so the later tiles of such rows overflow the
+    2^30 bound and must go through the careful path (maximum raised, output rescaled) and still match fp32."""
+    from pytorch_distributed_training_amd.ops import reference as ref_ops
+
+    torch.manual_seed(11)
+    dev = _dev()
+    d = h * 64
+    qkv = (torch.randn(b, s, 3 * d, device=dev) * amp).to(torch.bfloat16).requires_grad_(True)
+    out = ht.attention_qkv(qkv, h, causal)
+    qr = qkv.detach().float().requires_grad_(True)
+    ref = ref_ops.attention_qkv(qr, h, causal)
+    assert torch.isfinite(out.float()).all()
+    assert _rel(out, ref) < 1e-2
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(_r(g))
+    assert torch.isfinite(qkv.grad.float()).all()
+    floor = 1e-3 * ref.numel() ** 0.5  # a (nearly) zero reference gradient - one key - is compared absolutely
+    for i, tol in ((0, 2.5e-2), (1, 2.5e-2), (2, 1.5e-2)):
+        a, r = qkv.grad.view(b, s, 3, d)[:, :, i].float(), qr.grad.view(b, s, 3, d)[:, :, i]
+        assert float((a - r).norm() / r.norm().clamp_min(floor)) < tol, ("dq", "dk", "dv")[i]
+
+
 def test_vit_and_gpt2_tiny_train_on_gpu():
     from pytorch_distributed_training_amd import ops
     from pytorch_distributed_training_amd.models import build_model
