@@ -20,6 +20,7 @@ import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between ranks; must precede HIP start-up
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -13,4 +13,11 @@ throughput metering.
 
 __version__ = "0.1.0"
 
+import os as _os
+
+# Sharing device memory between the processes of a node (RCCL's peer-to-peer buffers over xGMI) goes through dmabuf
+# handles; hosts whose driver offers only that need the legacy IPC mode off *before* the HIP runtime starts, otherwise
+# communicator set-up with more than one rank fails in hipIpcGetMemHandle.  A value given by the user is kept.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 from . import utils  # noqa: F401
