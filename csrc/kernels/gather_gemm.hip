@@ -23,6 +23,7 @@
 // Role parity: the cuDNN/cuBLAS kernels behind `net(imgs)` / `losses.backward()` at
 // /root/reference/src/main.py:74,78.
 #include "common.h"
+#include <type_traits>
 
 
 #define GG_MAX_TAPS 49
@@ -1541,9 +1542,10 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     // out: column tile tc takes the K-steps s with s % tiles_c == tc, wave column wc the fragments i with
     // i % WC == wc; everything is added to dbias atomically at the end.
     const bool do_bias = p.dbias != nullptr;
-    f32x4 accb[FN];
+    constexpr int NB = (FN + WC - 1) / WC;  // fragments i with i % WC == wc: their sums live in accb[i / WC]
+    f32x4 accb[NB];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NB; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = f32_to_bf16(1.f);
@@ -1555,43 +1557,76 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     // is therefore awaited by hand (lgkmcnt(0), then a scheduling fence so no MFMA is hoisted above it).
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_void_t*)ring));
-    auto compute = [&](int slot, bool bias_step) {
+    // A K-step is worked off in units of (32-pixel slice kk, group of dY fragments): the fragment reads of the next unit
+    // are issued before the MFMAs of the current one and awaited with a counted lgkmcnt, so within a wave the LDS
+    // latency hides behind 16 MFMAs instead of being paid at the head of every slice.
+    auto compute = [&](int slot, const bool bias_step) {
+        constexpr int HG = FN >= 4 ? 2 : 1;  // groups of dY fragments per slice
+        constexpr int GI = FN / HG;
+        constexpr int UNITS = 2 * HG;
         const uint32_t yb = lds_base + static_cast<uint32_t>(slot * STAGE) * 2u;
         const uint32_t xb = yb + KM * BN * 2u;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {  // one 32-pixel slice at a time: half the fragment registers
-            s16x4 ylo[FN], yhi[FN], xlo[FC], xhi[FC];
+        s16x4 ylo[2][GI], yhi[2][GI], xlo[2][FC], xhi[2][FC];
+        auto issue_x = [&](int kk) {
             const int krow = kk * 32 + 4 * g + q;  // krow and krow + 16 swizzle alike
-            const int swy = swz_y(krow), swx = swz_x(krow);
-#pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int u = (wr * TN + i * 16) >> 4;
-                const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ swy) << 4) + 4 * pp) * 2u;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[i]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[i]) : "v"(a), "n"(16 * BN * 2) : "memory");
-            }
+            const int swx = swz_x(krow);
 #pragma unroll
             for (int j = 0; j < FC; ++j) {
                 const int u = (wc * TC + j * 16) >> 4;
                 const uint32_t a = xb + static_cast<uint32_t>(krow * BC + ((u ^ swx) << 4) + 4 * pp) * 2u;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[j]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[j]) : "v"(a), "n"(16 * BC * 2) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kk][j]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[kk][j]) : "v"(a), "n"(16 * BC * 2) : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto issue_y = [&](int kk, int h, int buf) {
+            const int krow = kk * 32 + 4 * g + q;
+            const int swy = swz_y(krow);
+#pragma unroll
+            for (int ii = 0; ii < GI; ++ii) {
+                const int u = (wr * TN + (h * GI + ii) * 16) >> 4;
+                const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ swy) << 4) + 4 * pp) * 2u;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[buf][ii]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[buf][ii]) : "v"(a), "n"(16 * BN * 2) : "memory");
+            }
+        };
+        issue_x(0);
+        issue_y(0, 0, 0);
+        auto unit = [&](auto un_c) {
+            constexpr int un = decltype(un_c)::value;
+            constexpr int kk = un / HG, h = un % HG, buf = un & 1;
+            if constexpr (un + 1 < UNITS) {
+                constexpr int kn = (un + 1) / HG, hn = (un + 1) % HG;
+                if constexpr (kn != kk) issue_x(kn);
+                issue_y(kn, hn, buf ^ 1);
+                // everything older than the reads just issued has to be back (the counter holds 15 at most)
+                constexpr int AHEAD = (kn != kk ? 2 * FC : 0) + 2 * GI;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD < 15 ? AHEAD : 15) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const s16x8 yv = {ylo[i][0], ylo[i][1], ylo[i][2], ylo[i][3], yhi[i][0], yhi[i][1], yhi[i][2], yhi[i][3]};
+            for (int ii = 0; ii < GI; ++ii) {
+                const int i = h * GI + ii;
+                const s16x8 yv = {ylo[buf][ii][0], ylo[buf][ii][1], ylo[buf][ii][2], ylo[buf][ii][3],
+                                  yhi[buf][ii][0], yhi[buf][ii][1], yhi[buf][ii][2], yhi[buf][ii][3]};
                 if (bias_step && (i % WC) == wc)
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), ones, accb[i], 0, 0, 0);
+                    accb[i / WC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), ones, accb[i / WC], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < FC; ++j) {
-                    const s16x8 xv = {xlo[j][0], xlo[j][1], xlo[j][2], xlo[j][3], xhi[j][0], xhi[j][1], xhi[j][2], xhi[j][3]};
+                    const s16x8 xv = {xlo[kk][j][0], xlo[kk][j][1], xlo[kk][j][2], xlo[kk][j][3],
+                                      xhi[kk][j][0], xhi[kk][j][1], xhi[kk][j][2], xhi[kk][j][3]};
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
                                                                          acc[i][j], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+        if constexpr (UNITS == 4) {
+            unit(std::integral_constant<int, 2>{});
+            unit(std::integral_constant<int, 3>{});
         }
     };
 
@@ -1646,7 +1681,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = n0 + wr * TN + i * 16 + (lane >> 4) * 4 + e;
-                if (n < p.N) __hip_atomic_fetch_add(p.dbias + n, accb[i][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n < p.N) __hip_atomic_fetch_add(p.dbias + n, accb[i / WC][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
