@@ -829,6 +829,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             stats_n0 = n0;
         }
         const int ncol = n0 + wn * TN + ech * 8;
+        const bool dense_out = p.ostr == 1 && p.oph == 0 && p.opw == 0 && p.OA == p.Hout && p.OB == p.Wout;
         // Output pixels of this lane's rows in a 16-row group and the loads of the epilogue operands that share the
         // output's layout (shortcut gradient, BatchNorm inputs, pre-activation).  Two register sets: the operands of
         // group i + 1 are requested before group i is staged and processed, so their latency is covered by a whole
@@ -844,12 +845,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 const int m = m0 + wm * TM + i * 16 + ps * RPP + erow;
                 rok_[st][ps] = m < p.M && ncol < p.N;
                 const int mc = min(m, p.M - 1);
-                const uint32_t img = fastdiv(mc, p.div_ab);
-                const uint32_t rem = mc - img * (p.OA * p.OB);
-                const uint32_t a = fastdiv(rem, p.div_b);
-                const uint32_t b = rem - a * p.OB;
-                pixo_[st][ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
-                                min(ncol, p.N - 8);
+                if (dense_out) {  // output pixel m is row m of Out (linear layers, stride-1 convolutions): no index arithmetic
+                    pixo_[st][ps] = static_cast<size_t>(mc) * p.ldo + min(ncol, p.N - 8);
+                } else {
+                    const uint32_t img = fastdiv(mc, p.div_ab);
+                    const uint32_t rem = mc - img * (p.OA * p.OB);
+                    const uint32_t a = fastdiv(rem, p.div_b);
+                    const uint32_t b = rem - a * p.OB;
+                    pixo_[st][ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
+                                    min(ncol, p.N - 8);
+                }
                 // operands with the layout of the output are read once: streamed past the caches when they are large
                 auto ld8 = [&](const bf16* q) {
                     bf16x8 r;
@@ -879,6 +884,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         for (int g = 0; g < AHEAD && g < FM; ++g) fetch(g, g % 3);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
+            if (p.out_nt == 3) break;  // (measurement aid: no epilogue at all, see pdt_set_out_nt_bytes)
             if (i + AHEAD < FM) fetch(i + AHEAD, (i + AHEAD) % 3);
             size_t(&pixo)[NPS] = pixo_[i % 3];
             bool(&rok)[NPS] = rok_[i % 3];
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                                 s3[e] += dz * (bf16_to_f32(y2v[ps][e]) - mu2[e]) * rs2[e];
                             }
                         }
-                    } else {
+                    } else if (p.stats != nullptr) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float f = bf16_to_f32(v[e]);
@@ -1120,7 +1126,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     a.stat_rows = bn_y != nullptr ? 3 : 2;
     a.xf = xf;
     a.act = act;
-    a.out_nt = g_out_nt_bytes < 0 ? 2 : (static_cast<long long>(M) * N * 2 >= g_out_nt_bytes);
+    a.out_nt = g_out_nt_bytes < 0 ? (g_out_nt_bytes == -2 ? 3 : 2) : (static_cast<long long>(M) * N * 2 >= g_out_nt_bytes);
     a.out2 = static_cast<bf16*>(out2);
     a.act_src = static_cast<const bf16*>(act_src);
     if (bn_y != nullptr && (smallc || tile < 10)) return -1;  // only the ring kernels have this epilogue
