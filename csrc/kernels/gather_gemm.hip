@@ -23,6 +23,7 @@
 // Role parity: the cuDNN/cuBLAS kernels behind `net(imgs)` / `losses.backward()` at
 // /root/reference/src/main.py:74,78.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 
@@ -1003,13 +1004,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing stages
 }
 
+// CUs the persistent grids are sized for.  PDT_RESERVE_CUS=k leaves k of them out: the 256-register ring kernels fill
+// a CU's register file, so a CU on which a collective's workgroup is resident cannot take its ring workgroup until that
+// one leaves, and with one workgroup per CU and tiles dealt out statically the launch then runs a second round; a
+// multi-GPU job that sees this can trade k CUs of every launch for it.
 static int pdt_num_cus() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
-        cus = n;
+        const char* e = getenv("PDT_RESERVE_CUS");
+        const int k = e ? atoi(e) : 0;
+        cus = k > 0 && k < n ? n - k : n;
     }
     return cus;
 }

@@ -456,7 +456,9 @@ _NUM_CUS = 0
 def _num_cus() -> int:
     global _NUM_CUS
     if _NUM_CUS == 0:
-        _NUM_CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        n = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        k = int(_os.environ.get("PDT_RESERVE_CUS", "0"))  # CUs left to the collectives' kernels (see pdt_num_cus)
+        _NUM_CUS = n - k if 0 < k < n else n
     return _NUM_CUS
 
 
