@@ -34,6 +34,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -115,6 +116,36 @@ __global__ void unpack_bf16_kernel(const uint4* __restrict__ src, float4* __rest
 // counts too: the counter is the evidence that a recorded step really contains its collectives.
 __global__ void count_kernel(unsigned long long* ctr) { atomicAdd(ctr, 1ull); }
 
+// Stand-in for the footprint of a multi-rank ring collective on ONE GPU (contention rehearsal, see
+// rehearsal_channels below): `channels` workgroups of 256 threads stay resident for as long as the bucket would take at
+// a given link rate.  They do not compute; what matters to the persistent one-workgroup-per-CU GEMM kernels is that a
+// CU with a resident wave of another kernel cannot take a workgroup that needs the whole register file.  The wait is
+// bounded by the constant-rate counter, so every wave leaves.
+__global__ __launch_bounds__(256) void resident_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+// PDT_REHEARSE_CHANNELS=c (with a one-rank collective kept by PDT_SELF_ALLREDUCE=1): c resident workgroups per bucket;
+// PDT_REHEARSE_GBPS: the rate the bucket's duration is derived from (default 150, about one xGMI link).
+int rehearsal_channels() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = std::getenv("PDT_REHEARSE_CHANNELS");
+        v = e ? std::atoi(e) : 0;
+    }
+    return v;
+}
+double rehearsal_gbps() {
+    static double v = -1.0;
+    if (v < 0) {
+        const char* e = std::getenv("PDT_REHEARSE_GBPS");
+        v = e ? std::atof(e) : 150.0;
+        if (v <= 0) v = 150.0;
+    }
+    return v;
+}
+
 int pack_grid(int64_t n8) {
     const int64_t blocks = (n8 + 255) / 256;
     return static_cast<int>(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
@@ -180,6 +211,12 @@ static bool bucket_collective(PdtRcclBuckets* s, int b) {
             return false;
         }
         s->bytes_on_wire += n * static_cast<int64_t>(dtype_bytes(dt));
+        if (c->world == 1 && rehearsal_channels() > 0) {
+            // ring all-reduce: every byte crosses a link twice; wall_clock64 ticks at 100 MHz
+            const double seconds = 2.0 * static_cast<double>(n) * dtype_bytes(dt) / (rehearsal_gbps() * 1e9);
+            resident_kernel<<<rehearsal_channels(), 256, 0, c->stream>>>(static_cast<long long>(seconds * 1e8) + 1);
+            if (!hip_ok(hipGetLastError(), "resident_kernel")) return false;
+        }
     }
     if (on_wire) {
         unpack_bf16_kernel<<<pack_grid(n / 8), 256, 0, c->stream>>>(static_cast<const uint4*>(buf),
