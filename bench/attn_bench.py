@@ -16,21 +16,25 @@ SHAPES = [("gpt2-medium b32", 32, 1024, 16, True), ("vit-b/16 b256", 256, 197, 1
           ("long 4k full", 4, 4096, 16, False)]
 
 
-def _time(run, iters=20):
-    # warm up for at least 30 ms: the first launches of a process run at a lower clock
+def _time(run, iters=20, warm_s=0.25, repeats=3):
+    # Warm up for a quarter of a second: the clocks of an idle GPU take ~0.2 s of load to settle (a backward pass
+    # timed 30 ms after start-up reads 10-15 % slower than the same launches inside a running job); median of three.
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.03:
+    while time.perf_counter() - t0 < warm_s:
         for _ in range(5):
             run()
         torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    times = []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    return sorted(times)[len(times) // 2]
 
 
 def main():

@@ -414,6 +414,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnArgs p) {
     const TileDma dma = tile_dma_setup(wave, lane);
     const FragAddr fa = frag_addr_setup(lane);
 
+    // the first two tiles are requested before the per-row operands, so the prologue pays one memory latency, not two
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < nt) {
+            tile_dma_issue(dma, kbase, srow, t * AT_T, p.S - 1, sKb[t], wave);
+            tile_dma_issue(dma, vbase, srow, t * AT_T, p.S - 1, sVb[t], wave);
+        }
     bf16x8 qf[4], dof[4];
     float nl = 0.f;    // minus the row's log-sum-exp (log2 units)
     f32x16 ndelta;
@@ -437,16 +444,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) ndelta[e] = -dl;
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (t < nt) {
-            tile_dma_issue(dma, kbase, srow, t * AT_T, p.S - 1, sKb[t], wave);
-            tile_dma_issue(dma, vbase, srow, t * AT_T, p.S - 1, sVb[t], wave);
-        }
     f32x16 dq[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[0][e] = dq[1][e] = 0.f;
     const int key_limit = p.causal ? min(qrow, p.S - 1) : p.S - 1;
+    const int wave_last_key = p.causal ? min(qw0 + 31, p.S - 1) : p.S - 1;
     const uint32_t sk_lds = lds_addr(&sKb[0][0]), sv_lds = lds_addr(&sVb[0][0]);
 
     int buf = 0;
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnArgs p) {
         // two halves of 32 keys, one after the other: S^T and dP^T of a half, its vector-ALU work, its share of dQ^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1 && k0 + 32 > wave_last_key) break;  // no query of the wave reaches the second half
             f32x16 s, dp;
             {
                 RowFrags kf, vf;
@@ -581,6 +584,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
         // (r & 3) + 8 (r >> 2) + 4 hi, so a lane needs four float4 of the half's lse / -delta rows
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
+            // a half none of whose queries sees any key of the wave: past the end, or wholly before the wave's keys
+            if (qt == 0 ? (p.causal && q0 + 31 < kw0) : (q0 + 32 >= p.S)) continue;
             f32x16 s, dp;
             {
                 RowFrags qf;
