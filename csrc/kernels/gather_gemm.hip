@@ -404,7 +404,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     constexpr int AI = (BM / PR) / NW, BI = (BN / PR) / NW; // LDS-DMA instructions per wave and stage
     constexpr int LPW = AI + BI;
     constexpr int STAGE = (BM + BN) * BK;                  // elements per ring stage: [A tile | B tile]
-    constexpr int EP = TN;                                 // pitch of the wave-private epilogue rows (chunks XOR-swizzled by row)
+    constexpr int EP = TN;                                 // pitch of the wave-private epilogue rows: 16-byte slots XOR-ed with the row, and in rows 8-15 the
+                                                           // two 8-byte halves of a slot exchanged - the 16 lanes of a ds_write_b64 group (one row each, banks modulo
+                                                           // 128 bytes) then cover every bank once
     constexpr int CH = TN / 8;                             // 16-byte chunks per epilogue row
     constexpr int RPP = 64 / CH;                           // rows per epilogue pass
     static_assert(BK == 32 || BK == 64, "K-step of 32 or 64");
@@ -907,12 +909,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(acc[i][j][e] + bv[e]);
                 const int er = lane & 15;
-                *reinterpret_cast<bf16x4*>(epi + er * EP + ((((nl >> 3) ^ er) & (CH - 1)) << 3) + (nl & 4)) = v;
+                *reinterpret_cast<bf16x4*>(epi + er * EP + ((((nl >> 3) ^ er) & (CH - 1)) << 3) + ((nl ^ (er >> 1)) & 4)) = v;
             }
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
                 const int row = ps * RPP + erow;
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(epi + row * EP + (((ech ^ row) & (CH - 1)) << 3));
+                // rows 8-15 were staged with the two 8-byte halves of every 16-byte slot exchanged (see the staging layout)
+                if (RPP <= 8 ? ((ps * RPP) & 8) != 0 : (row & 8) != 0) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
                 if (rok[ps]) {
                     const size_t o = pixo[ps];
                     if (EPI & 2) {
