@@ -1397,9 +1397,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 // is transformed in place in LDS after it has landed (a thread rewrites its 16-byte chunks with the scale / shift of
 // their channels from a table in LDS), then a second barrier.  Rows beyond the pixel range hold relu(shift) instead of
 // zero after that, which is harmless: the dY rows they are multiplied with are zero.
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF = false>
+//
+// PP ("ping-pong", 256x256 tile, 2 x 4 waves, two stages, PLAIN only; see gather_gemm_ring_kernel): a K-step is cut
+// into four phases of 16 MFMAs - (32-pixel slice, half of the wave's dY fragments) - each bracketed by two workgroup
+// barriers, and wave row 1 runs one barrier behind wave row 0, so on every SIMD one wave issues MFMAs while the other
+// issues its transposed fragment reads and LDS-DMA requests.  Operands are staged in four units of 32 pixel rows per
+// K-step, in the order {X rows 0-31, dY rows 0-31, X rows 32-63, dY rows 32-63}, one unit per phase, six units
+// ahead of the reads; a counted wait leaves four units in flight across the barriers.  With that order a unit is
+// overwritten no earlier than a full phase after its last reader's MFMAs, for either wave row.
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF = false, bool PP = false>
 __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, int gx, int nblocks) {
     static_assert(!XF || (PLAIN && MODE == 0), "operand transform: single-tap launches");
+    static_assert(!PP || (PLAIN && !XF && MODE == 0 && BN == 256 && BC == 256 && WN == 2 && WC == 4 && NS == 2),
+                  "ping-pong schedule: 256x256, 2x4 waves, single tap");
     constexpr int KM = 64;                       // pixels per K-step
     constexpr int NW = WN * WC;
     constexpr int TN = BN / WN, TC = BC / WC;    // per-wave tile
@@ -1446,10 +1456,20 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     // loader: lane -> (row inside a piece, physical chunk); the logical chunk it fetches undoes the swizzle
     const int y_lr = lane / YCH, y_pc = lane % YCH;
     const int x_lr = lane / XCH, x_pc = lane % XCH;
+    // First tile row of this wave's DMA piece i.  Plain ring: consecutive pieces.  Ping-pong: pieces 2i' and 2i' + 1 of
+    // the 32-row staging unit i >> 1 (sixteen 2-row pieces per unit, two per wave).
+    auto y_row0 = [&](int i) {
+        if constexpr (PP) return (i >> 1) * 32 + (2 * wave + (i & 1)) * YR;
+        else return (wave * YI + i) * YR;
+    };
+    auto x_row0 = [&](int i) {
+        if constexpr (PP) return (i >> 1) * 32 + (2 * wave + (i & 1)) * XR;
+        else return (wave * XI + i) * XR;
+    };
     int x_dh[XI], x_dw[XI], x_cc[XI];  // per piece: tap offset and channel (MODE 0) / kernel row, -, position (MODE 1)
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int row = (wave * XI + i) * XR + x_lr;
+        const int row = x_row0(i) + x_lr;
         const int j = c0 + ((((x_pc >> 1) ^ swz_x(row)) << 1) | (x_pc & 1)) * 8;  // first of this lane's 8 columns
         if (j >= KC) {
             x_dh[i] = -(1 << 24);
@@ -1515,7 +1535,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     if constexpr (PLAIN) {
 #pragma unroll
         for (int i = 0; i < YI; ++i) {
-            const int row = (wave * YI + i) * YR + y_lr;
+            const int row = y_row0(i) + y_lr;
             const int c = ((((y_pc >> 1) ^ swz_y(row)) << 1) | (y_pc & 1)) * 8;
             const bool ok = n0 + c < p.N;
             y_ptr[i] = ok ? p.dY + static_cast<size_t>(ms + row) * p.ldy + n0 + c : p.zeros;
@@ -1523,7 +1543,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
         }
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            const int row = (wave * XI + i) * XR + x_lr;
+            const int row = x_row0(i) + x_lr;
             const bool ok = x_dh[i] > -(1 << 23);
             x_ptr[i] = ok ? p.X + static_cast<size_t>(ms + row) * p.C + x_cc[i] : p.zeros;
             x_adv[i] = ok ? static_cast<size_t>(KM) * p.C : 0;
@@ -1547,6 +1567,32 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
         }
         ++ld_issued;
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
+    };
+    // ping-pong: staging unit r of the K-step under the loader's cursor (0: X rows 0-31, 1: dY rows 0-31, 2: X rows
+    // 32-63, 3: dY rows 32-63); after the last unit the cursor moves to the next K-step
+    auto pp_unit = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const int mbase = ms + ld_issued * KM;
+        bf16* sY = ring + ld_slot * STAGE;
+        bf16* sX = sY + KM * BN;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            constexpr int half = r >> 1;
+            const int i = 2 * half + k;
+            if constexpr (r & 1) {
+                const bool ok = mbase + y_row0(i) + y_lr < me;
+                __builtin_amdgcn_global_load_lds((global_cvoid_t*)(ok ? y_ptr[i] : p.zeros), (lds_void_t*)(sY + y_row0(i) * BN), 16, 0, 0);
+                y_ptr[i] += y_adv[i];
+            } else {
+                const bool ok = mbase + x_row0(i) + x_lr < me;
+                __builtin_amdgcn_global_load_lds((global_cvoid_t*)(ok ? x_ptr[i] : p.zeros), (lds_void_t*)(sX + x_row0(i) * BC), 16, 0, 0);
+                x_ptr[i] += x_adv[i];
+            }
+        }
+        if constexpr (r == 3) {
+            ++ld_issued;
+            ld_slot ^= 1;
+        }
     };
 
     f32x4 acc[FN][FC];
@@ -1647,13 +1693,88 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
         }
     };
 
+    int slot = 0;
+    int bias_turn = do_bias ? tc : -1;  // counts down to this workgroup's next bias K-step
+    if constexpr (PP) {
+        using U0 = std::integral_constant<int, 0>;
+        using U1 = std::integral_constant<int, 1>;
+        using U2 = std::integral_constant<int, 2>;
+        using U3 = std::integral_constant<int, 3>;
+        constexpr int GI = FN / 2;  // dY fragments of a phase
+        // six units ahead: the whole first K-step and the first two units of the second
+        pp_unit(U0{}); pp_unit(U1{}); pp_unit(U2{}); pp_unit(U3{}); pp_unit(U0{}); pp_unit(U1{});
+        // four units (two DMA instructions each per wave) may stay in flight: the first two have landed
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if (wr == 1) asm volatile("s_barrier" ::: "memory");  // wave row 1 runs one barrier behind row 0 from here on
+        for (int s = 0; s < nsteps; ++s) {
+            const bool bias_step = bias_turn == 0;
+            const uint32_t yb = lds_base + static_cast<uint32_t>(slot * STAGE) * 2u;
+            const uint32_t xb = yb + KM * BN * 2u;
+            // fragment registers alternate between phases (dY) and slices (X): a read never targets registers that MFMAs
+            // issued just before still name as sources
+            s16x4 ylo[2][GI], yhi[2][GI], xlo[2][FC], xhi[2][FC];
+            // One phase: DMA unit for a later K-step, this phase's fragment reads -> counted wait that retires the unit
+            // the next phase reads -> barrier -> reads back -> 16 MFMAs at raised priority -> barrier.
+            auto phase = [&](auto phc, auto unitc) {
+                constexpr int ph = decltype(phc)::value;
+                constexpr int kk = ph >> 1, h = ph & 1, buf = ph & 1;
+                pp_unit(unitc);
+                const int krow = kk * 32 + 4 * g + q;  // krow and krow + 16 swizzle alike
+                if constexpr (h == 0) {
+                    const int swx = swz_x(krow);
+#pragma unroll
+                    for (int j = 0; j < FC; ++j) {
+                        const int u = (wc * TC + j * 16) >> 4;
+                        const uint32_t a = xb + static_cast<uint32_t>(krow * BC + ((u ^ swx) << 4) + 4 * pp) * 2u;
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kk][j]) : "v"(a) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[kk][j]) : "v"(a), "n"(16 * BC * 2) : "memory");
+                    }
+                }
+                const int swy = swz_y(krow);
+#pragma unroll
+                for (int ii = 0; ii < GI; ++ii) {
+                    const int u = (wr * TN + (h * GI + ii) * 16) >> 4;
+                    const uint32_t a = yb + static_cast<uint32_t>(krow * BN + ((u ^ swy) << 4) + 4 * pp) * 2u;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[buf][ii]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[buf][ii]) : "v"(a), "n"(16 * BN * 2) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ii = 0; ii < GI; ++ii) {
+                    const int i = h * GI + ii;
+                    const s16x8 yv = {ylo[buf][ii][0], ylo[buf][ii][1], ylo[buf][ii][2], ylo[buf][ii][3],
+                                      yhi[buf][ii][0], yhi[buf][ii][1], yhi[buf][ii][2], yhi[buf][ii][3]};
+                    if (bias_step && (i % WC) == wc)
+                        accb[i / WC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), ones, accb[i / WC], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FC; ++j) {
+                        const s16x8 xv = {xlo[kk][j][0], xlo[kk][j][1], xlo[kk][j][2], xlo[kk][j][3],
+                                          xhi[kk][j][0], xhi[kk][j][1], xhi[kk][j][2], xhi[kk][j][3]};
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
+                                                                             acc[i][j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            phase(U0{}, U2{});
+            phase(U1{}, U3{});
+            phase(U2{}, U0{});
+            phase(U3{}, U1{});
+            if (do_bias) bias_turn = bias_step ? tiles_c - 1 : bias_turn - 1;
+            slot ^= 1;
+        }
+        if (wr == 0) asm volatile("s_barrier" ::: "memory");  // pairs with the last barrier of wave row 1
+    } else {
 #pragma unroll
     for (int k = 0; k < NS - 1; ++k) {
         if constexpr (PLAIN) plain_issue();
         else if (ld_issued < nsteps) issue_stage();
     }
-    int slot = 0;
-    int bias_turn = do_bias ? tc : -1;  // counts down to this workgroup's next bias K-step
     for (int s = 0; s < nsteps; ++s) {
         if constexpr (PLAIN) {
             wait_vm_and_barrier<(NS - 2) * LPW>();  // NS - 1 stages are always in flight here
@@ -1688,6 +1809,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
         compute(slot, bias_step);
         if (do_bias) bias_turn = bias_step ? tiles_c - 1 : bias_turn - 1;
         slot = slot + 1 == NS ? 0 : slot + 1;
+    }
     }
 
     if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing zero-page stages
@@ -1724,24 +1846,24 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     }
 }
 
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false, bool XF = false>
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN = false, bool XF = false, bool PP = false>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_kernel(const WgradArgs p) {
-    wgrad_ring_body<BN, BC, WN, WC, NS, MODE, PLAIN, XF>(p, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.x * gridDim.y);
+    wgrad_ring_body<BN, BC, WN, WC, NS, MODE, PLAIN, XF, PP>(p, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.x * gridDim.y);
 }
 
 // Two independent weight-gradient problems of the same tile shape in one launch (workgroups [0, n0) belong to the
 // first).  A workgroup's fp32 atomics are fire-and-forget, so when the first problem's workgroups retire the
 // second problem's main loops start on the freed CUs while those atomics are still draining at the L2: the
 // atomic tail of the first problem - a quarter of its run time on transformer shapes - is no longer exposed.
-template <int BN, int BC, int WN, int WC, int NS>
+template <int BN, int BC, int WN, int WC, int NS, bool PP = false>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_ring_dual_kernel(const WgradArgs p0, const WgradArgs p1, int gx0, int n0,
                                                                       int gx1, int n1) {
     const int b = blockIdx.x;
-    if (b < n0) wgrad_ring_body<BN, BC, WN, WC, NS, 0, true>(p0, b, gx0, n0);
-    else wgrad_ring_body<BN, BC, WN, WC, NS, 0, true>(p1, b - n0, gx1, n1);
+    if (b < n0) wgrad_ring_body<BN, BC, WN, WC, NS, 0, true, false, PP>(p0, b, gx0, n0);
+    else wgrad_ring_body<BN, BC, WN, WC, NS, 0, true, false, PP>(p1, b - n0, gx1, n1);
 }
 
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF = false>
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF = false, bool PP = false>
 static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream);
 
 template <int BN, int BC, int WN, int WC, int NS, int MODE = 0>
@@ -1757,12 +1879,12 @@ static int launch_wgrad_ring(const WgradArgs& a, int gy, hipStream_t stream) {
     return launch_wgrad_ring_plain<BN, BC, WN, WC, NS, MODE, false>(a, gy, stream);
 }
 
-template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF>
+template <int BN, int BC, int WN, int WC, int NS, int MODE, bool PLAIN, bool XF, bool PP>
 static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t stream) {
     constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16) + (XF ? 2 * BC * sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "ring does not fit the LDS of a CU");
     if (a.zeros == nullptr) return -1;
-    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE, PLAIN, XF>;
+    auto kernel = wgrad_ring_kernel<BN, BC, WN, WC, NS, MODE, PLAIN, XF, PP>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -1778,10 +1900,10 @@ static bool wgrad_is_plain(const WgradArgs& a) {
     return a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && a.istr == 1 && a.OA == a.Hin && a.OB == a.Win;
 }
 
-template <int BN, int BC, int WN, int WC, int NS>
+template <int BN, int BC, int WN, int WC, int NS, bool PP = false>
 static int launch_wgrad_ring_dual(const WgradArgs& a0, int gy0, const WgradArgs& a1, int gy1, hipStream_t stream) {
     constexpr size_t lds = static_cast<size_t>(NS) * 64 * (BN + BC) * sizeof(bf16);
-    auto kernel = wgrad_ring_dual_kernel<BN, BC, WN, WC, NS>;
+    auto kernel = wgrad_ring_dual_kernel<BN, BC, WN, WC, NS, PP>;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -1824,6 +1946,7 @@ PDT_API int pdt_wgrad_group_end(void* stream) {
             else if (u.tile == 11) r = launch_wgrad_ring_dual<256, 128, 4, 2, 3>(u.a, u.gy, v.a, v.gy, s);
             else if (u.tile == 12) r = launch_wgrad_ring_dual<128, 256, 2, 4, 3>(u.a, u.gy, v.a, v.gy, s);
             else if (u.tile == 16) r = launch_wgrad_ring_dual<256, 256, 2, 4, 2>(u.a, u.gy, v.a, v.gy, s);
+            else if (u.tile == 17) r = launch_wgrad_ring_dual<256, 256, 2, 4, 2, true>(u.a, u.gy, v.a, v.gy, s);
             if (r != -2) {
                 rc = r;
                 i += 2;
@@ -1886,7 +2009,9 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (wgrad_grouping && (tile == 10 || tile == 11 || tile == 12 || tile == 16) && wgrad_npending < 4) {
+    // tile 17 = the 256x256 tile on the ping-pong schedule; it needs the single-tap form and no operand transform
+    if (tile == 17 && (!wgrad_is_plain(a) || xf != nullptr)) tile = 16;
+    if (wgrad_grouping && (tile == 10 || tile == 11 || tile == 12 || tile == 16 || tile == 17) && wgrad_npending < 4) {
         if (a.zeros == nullptr) return -1;
         wgrad_pending[wgrad_npending].a = a;
         wgrad_pending[wgrad_npending].tile = tile;
@@ -1919,6 +2044,8 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         return launch_wgrad_ring<128, 256, 2, 4, 3>(a, gy, s);
     } else if (tile == 16) {
         return launch_wgrad_ring<256, 256, 2, 4, 2>(a, gy, s);
+    } else if (tile == 17) {
+        return launch_wgrad_ring_plain<256, 256, 2, 4, 2, 0, true, false, true>(a, gy, s);
     } else if (tile == 13) {
         return launch_wgrad_ring<64, 256, 2, 4, 3>(a, gy, s);
     } else if (tile == 14) {
@@ -1934,5 +2061,6 @@ static int wgrad_launch_one(const WgradArgs& a, int tile, int gy, hipStream_t s)
     if (tile == 11) return launch_wgrad_ring<256, 128, 4, 2, 3>(a, gy, s);
     if (tile == 12) return launch_wgrad_ring<128, 256, 2, 4, 3>(a, gy, s);
     if (tile == 16) return launch_wgrad_ring<256, 256, 2, 4, 2>(a, gy, s);
+    if (tile == 17) return launch_wgrad_ring_plain<256, 256, 2, 4, 2, 0, true, false, true>(a, gy, s);
     return -1;
 }

@@ -540,6 +540,9 @@ WGRAD_GROUP = int(_os.environ.get("PDT_WGRAD_GROUP", "1"))  # 0: never pair weig
 WGRAD_RING = int(_os.environ.get("PDT_WGRAD_RING", "1"))  # 0: one-step register-staged kernel everywhere
 # ring kernels hold one workgroup per CU: one full round of workgroups, not two (twice the atomic volume)
 WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "0"))  # 0: the number of CUs
+# Single-tap 256x256 weight gradients run on the ping-pong schedule (tile 17: the two wave rows of a workgroup alternate
+# between MFMA and LDS / DMA phases, as in the forward GEMM); 0 switches it off.
+WGRAD_PP = int(_os.environ.get("PDT_WGRAD_PP", "1"))
 
 
 def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int] = None, target: Optional[int] = None) -> int:
@@ -604,9 +607,11 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         tile = 13  # 64 x 256: all output channels of a narrow layer, several taps per tile
     elif WGRAD_RING and N >= 256 and kc < 128:
         tile = 14  # 256 x 64
+    if tile == 16 and WGRAD_PP and len(taps) == 1 and xf is None:
+        tile = 17  # (the launcher falls back to 16 when the tap is not the identity mapping)
     if tile >= 10:
         bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256), 13: (64, 256), 14: (256, 64), 15: (64, 256),
-                  16: (256, 256)}[tile]
+                  16: (256, 256), 17: (256, 256)}[tile]
         splits = _wgrad_splits(M, N, kc, 1, bn, bc, WGRAD_RING_TARGET_BLOCKS or _num_cus())
     else:
         tile = 0 if (N > 64 and C > 64 and not smallc) else 1

@@ -106,6 +106,24 @@ def test_linear_ring_variant_with_bias(hip, monkeypatch, tile):
     test_linear_forward_backward(hip, 3000, 256, 1000, True)
 
 
+@pytest.mark.parametrize("tile,pp", [(10, 0), (11, 0), (12, 0), (16, 0), (16, 1)])
+@pytest.mark.parametrize("m,n,k", [(4133, 520, 328), (16384, 1024, 768), (700, 256, 256)])
+def test_weight_gradient_ring_tiles_against_fp32(hip, monkeypatch, tile, pp, m, n, k):
+    """dW = dY^T X and the bias gradient (column sums of dY) from every ring tile of the weight-gradient kernel,
+    the 256x256 tile on both of its schedules (pp = 1: ping-pong), on ragged row counts and partial tiles."""
+    monkeypatch.setattr(hip, "WGRAD_RING", tile)
+    monkeypatch.setattr(hip, "WGRAD_PP", pp)
+    torch.manual_seed(5)
+    dev = _dev()
+    dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
+    x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    dw = torch.zeros(n, k, device=dev)
+    db = torch.zeros(n, device=dev)
+    assert hip._launch_wgrad(dy, x, dw, m, n, n, k, [(0, 0, 0)], k, 1, 1, 1, 1, 1, dbias=db)
+    assert _rel_err(dw, dy.float().t() @ x.float()) < 2e-3
+    assert _rel_err(db, dy.float().sum(0)) < 2e-3
+
+
 @pytest.mark.parametrize("m,k,n,wide", [(4096, 1024, 1024, None), (197 * 16, 768, 768, None), (3000, 256, 1024, 13), (3000, 256, 1024, 16), (500, 3072, 768, 0)])
 def test_linear_with_bias_and_residual_in_the_epilogue(hip, monkeypatch, m, k, n, wide):
     """x W^T + bias + residual from one GEMM; the bias gradient comes out of the weight-gradient kernel when it
