@@ -72,8 +72,9 @@ from .train import TrainConfig, run_training
               help="steps between the ranks' agreements on stop requests (0: every step on CPU, every 16 on GPU)")
 @click.option("--profile", type=str, default="", help="write a chrome trace of host-side phases to this path")
 @click.option("--check-finite", is_flag=True, default=False)
-@click.option("--hip-graph", is_flag=True, default=False,
-              help="record the whole training step into a hipGraph after --graph-after eager steps (launch-bound configs)")
+@click.option("--hip-graph/--no-hip-graph", default=None,
+              help="record the whole training step into a hipGraph after --graph-after eager steps (launch-bound configs); "
+                   "default: automatic - on for single-GPU image runs of at most 64 x 224 x 224 input pixels per batch")
 @click.option("--graph-after", type=int, default=3, show_default=True)
 def main(**kwargs):
     cfg = TrainConfig(**kwargs)
