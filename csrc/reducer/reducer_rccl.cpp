@@ -1,7 +1,7 @@
 // RCCL transport for the gradient-bucket reducer.
 //
 // One communicator per process (one process per GPU).  All collectives are issued on a
-// dedicated, high-priority HIP stream owned by this file; ordering against the stream the
+// dedicated non-blocking HIP stream owned by this file; ordering against the stream the
 // training step runs on is expressed only with HIP events, so backward kernels and bucket
 // collectives overlap:
 //
@@ -264,7 +264,14 @@ int pdt_rccl_unique_id(char* out) {
     return 0;
 }
 
-PdtComm* pdt_rccl_comm_create(const char* id_bytes, int rank, int world, int device, int high_priority) {
+// `priority`: 0 = the priority of ordinary streams (default), 1 = the device's highest, -1 = its lowest.
+// The communication stream spends most of its life waiting (a barrier packet on a "bucket ready" event of the step's
+// stream).  On a raised-priority hardware queue that wait is a priority inversion once the process has more streams
+// than the packet processor serves at a time (step stream + copy stream + torch's own communicator stream + this one):
+// the waiting queue keeps being served ahead of the queues that would produce the event, the device stops making
+// progress and the host blocks in its next kernel launch.  Observed on MI355X with a one-rank group, ResNet-50 at batch
+// 256 with a prefetching copy stream: hung in the second step at priority 1, fine at 0 and -1.
+PdtComm* pdt_rccl_comm_create(const char* id_bytes, int rank, int world, int device, int priority) {
     if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
     auto* c = new PdtComm();
     c->rank = rank;
@@ -275,7 +282,9 @@ PdtComm* pdt_rccl_comm_create(const char* id_bytes, int rank, int world, int dev
         delete c;
         return nullptr;
     }
-    if (!hip_ok(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? hi : lo),
+    // (lo is the numerically greatest value = lowest priority; ordinary streams have priority 0)
+    const int prio = priority > 0 ? hi : (priority < 0 ? lo : (lo < 0 ? lo : (hi > 0 ? hi : 0)));
+    if (!hip_ok(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio),
                 "hipStreamCreateWithPriority") ||
         !hip_ok(hipEventCreateWithFlags(&c->fence_in, hipEventDisableTiming), "hipEventCreate") ||
         !hip_ok(hipEventCreateWithFlags(&c->fence_out, hipEventDisableTiming), "hipEventCreate")) {

@@ -3,7 +3,7 @@
 A transport turns "bucket k is complete" into an asynchronous all-reduce and later makes
 the consumer of the gradients wait for it.  Three exist:
 
-* :class:`RcclTransport`    - own RCCL communicator on a dedicated high-priority HIP stream
+* :class:`RcclTransport`    - own RCCL communicator on a dedicated HIP stream
   (``csrc/reducer/reducer_rccl.cpp``); the bucket launch and wait run entirely in C++.
 * :class:`TorchDistTransport` - ``torch.distributed`` async all-reduce (gloo on CPU); the C++
   core calls back into Python.
@@ -190,7 +190,17 @@ class RcclComm:
 
     _counter = 0
 
-    def __init__(self, rank: int, world_size: int, device: torch.device, store=None, high_priority: bool = True):
+    PRIORITIES = {"normal": 0, "high": 1, "low": -1}
+
+    def __init__(self, rank: int, world_size: int, device: torch.device, store=None, priority: Optional[str] = None):
+        """``priority`` of the communication stream: ``normal`` (default; ``PDT_COMM_PRIORITY`` overrides), ``high`` or
+        ``low``.  A raised priority looks attractive for collectives but is a priority inversion on this hardware: the
+        stream mostly *waits* for bucket-ready events, and once the process has more streams than hardware queues
+        served at a time (a prefetcher's copy stream is enough) the waiting high-priority queue starves the queues
+        that would produce the event and the device hangs."""
+        priority = priority or os.environ.get("PDT_COMM_PRIORITY", "normal")
+        if priority not in self.PRIORITIES:
+            raise ValueError(f"communication stream priority must be one of {sorted(self.PRIORITIES)}")
         self._lib = native.rccl()
         self.rank, self.world_size, self.device = rank, world_size, torch.device(device)
         nbytes = self._lib.pdt_rccl_unique_id_bytes()
@@ -210,7 +220,8 @@ class RcclComm:
             buf = ctypes.create_string_buffer(nbytes)
             self._check(self._lib.pdt_rccl_unique_id(buf), "ncclGetUniqueId")
             uid = buf.raw
-        self._h = self._lib.pdt_rccl_comm_create(uid, rank, world_size, self.device.index or 0, int(high_priority))
+        self.priority = priority
+        self._h = self._lib.pdt_rccl_comm_create(uid, rank, world_size, self.device.index or 0, self.PRIORITIES[priority])
         if not self._h:
             raise RcclError(f"RCCL communicator creation failed: {self._lib.pdt_rccl_last_error().decode()}")
 

@@ -2,6 +2,8 @@
 group has a single rank; the code path (own communicator, dedicated stream, event ordering, bucket launch
 from autograd hooks, finalize before the optimizer) is the one N-rank jobs take."""
 import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -239,3 +241,16 @@ def test_bench_py_prints_one_json_line_with_sync_proofs():
     ex = rec["extras"]
     assert ex["transport"] == "RcclTransport" and ex["rccl_ranks"] == 1 and ex["params_in_sync"] is True
     assert ex["rank_sum"]["got"] == ex["rank_sum"]["expected"] == 1.0 and "error" not in ex
+
+
+@pytest.mark.parametrize("main", ["null", "pool"])
+def test_data_parallel_step_with_a_prefetch_stream_and_host_run_ahead_makes_progress(main, free_port):
+    """Step stream + copy stream + communication stream + torch's communicator stream, host several steps ahead:
+    with a raised-priority communication stream this constellation stopped the device (the waiting priority queue
+    starved the queues that produce what it waits for); the communicator's stream has ordinary priority."""
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_stream_worker.py")
+    env = dict(os.environ, PORT=str(free_port), PROBE_MODEL="resnet50", PROBE_BATCH="256", PROBE_SIZE="224",
+               PROBE_STEPS="20", PROBE_LIMIT="60", PROBE_MAIN=main)
+    env.pop("PDT_COMM_PRIORITY", None)
+    r = subprocess.run([sys.executable, "-u", worker], env=env, capture_output=True, text=True, timeout=120)
+    assert "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
