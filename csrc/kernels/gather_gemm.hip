@@ -368,7 +368,10 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // EPI selects what the epilogue reads besides the accumulators (bit mask): 1 bias, 2 addend (+ mask bits),
 // 4 BatchNorm-backward sums with the ReLU mask recomputed from bn_y, 8 the same with the mask from bn_bits,
 // 16 result times gelu'(act_src), 32 gelu(result) stored to out2 as well, 64 (with 8) sums for a second BatchNorm
-// that shares dz (the shortcut BatchNorm of a projected block tail).
+// that shares dz (the shortcut BatchNorm of a projected block tail), 128 no channel statistics at all (a launch
+// without a statistics request: the partial sums carried across tiles would only cost registers - on the ping-pong
+// schedule, which runs at the 256-register limit, they made the compiler spill, and every reload of a spilled
+// value in the epilogue is a vmcnt(0) wait that also drains the stores and the operand prefetch in flight).
 // It is a template parameter because an ordinary load anywhere on the path makes the compiler drain the
 // DMA queue (vmcnt(0)) at its use.
 //
@@ -420,6 +423,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     const int wm = wave / WN, wn = wave % WN;
     bf16* epi = ring + NS * STAGE + wave * 16 * EP;
     float* xf_tab = reinterpret_cast<float*>(ring + NS * STAGE + NW * 16 * EP);  // XF: [2][C] scale, shift
+    // Ping-pong schedule with a bias: the TN bias values of this wave's columns are fetched once per tile by LDS-DMA
+    // (wave-private row behind the epilogue staging area), issued in front of the tile's K-loop and retired by its
+    // counted waits long before the epilogue reads them.  Loading them with ordinary loads inside the epilogue - 16 per
+    // lane for each of the 8 row groups - made every group wait for vmcnt(0): for its own loads, for the stores of the
+    // group before it and for the next tile's operand prefetch.
+    constexpr bool BIAS_LDS = PP && (EPI & 1);
+    static_assert(!BIAS_LDS || TN == 64, "one bias value per lane");
+    float* bias_row = reinterpret_cast<float*>(ring + NS * STAGE + NW * 16 * EP) + wave * TN;
     if constexpr (XF) {
         for (int i = tid; i < 2 * p.C; i += NW * 64) xf_tab[i] = p.xf[2 * p.C + i];
         __syncthreads();
@@ -643,13 +654,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     };
 
     // BatchNorm partial sums of this lane's 8 channels, carried across tiles
+    constexpr bool NOSTATS = (EPI & 128) != 0;
+    static_assert(!NOSTATS || (EPI & 12) == 0, "BatchNorm-backward sums are statistics");
     const int ech = lane % CH, erow = lane / CH;
     float s1[8], s2[8], s3[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
     int stats_n0 = -1;
     auto flush_stats = [&]() {
-        if (p.stats == nullptr || stats_n0 < 0) return;
+        if (NOSTATS || p.stats == nullptr || stats_n0 < 0) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -720,6 +733,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        if constexpr (BIAS_LDS) {
+            const float* src = p.bias + min(n0 + wn * TN + lane, p.N - 1);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)bias_row, 4, 0, 0);
+        }
         if constexpr (PP) {
             for (int s = 0; s < nsteps; ++s, ++g) {
                 const bf16* sA = ring + slot * STAGE;
@@ -900,7 +917,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             for (int j = 0; j < FN; ++j) {
                 const int nl = j * 16 + (lane >> 4) * 4;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (EPI & 1) {
+                if constexpr (BIAS_LDS) {
+                    bv = *reinterpret_cast<const f32x4*>(bias_row + nl);  // (an LDS read per fragment: no registers held across the tile)
+                } else if (EPI & 1) {
                     const int n = n0 + wn * TN + nl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bv[e] = p.bias[min(n + e, p.N - 1)];
@@ -986,7 +1005,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                                 s3[e] += dz * (bf16_to_f32(y2v[ps][e]) - mu2[e]) * rs2[e];
                             }
                         }
-                    } else if (p.stats != nullptr) {
+                    } else if (!NOSTATS && p.stats != nullptr) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float f = bf16_to_f32(v[e]);
@@ -1039,7 +1058,9 @@ static int launch_gather_gemm_ring_epi(const GatherGemmArgs& a, hipStream_t stre
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK, bool PLAIN, bool PP, bool XF>
 static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t stream) {
     if ((a.C % BK) != 0) return -1;
-    constexpr size_t lds_base = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16);
+    // (+ one row of bias values per wave on the ping-pong schedule, see the kernel)
+    constexpr size_t lds_base = (static_cast<size_t>(NS) * (BM + BN) * BK + static_cast<size_t>(WM * WN) * 16 * (BN / WN)) * sizeof(bf16) +
+                                ((PP && (EPI & 1)) ? static_cast<size_t>(WM * WN) * (BN / WN) * sizeof(float) : 0);
     static_assert(lds_base <= 160 * 1024, "ring does not fit the LDS of a CU");
     const size_t lds = lds_base + (XF ? static_cast<size_t>(a.C) * 2 * sizeof(float) : 0);  // + the scale / shift table
     if (lds > 160 * 1024) return -1;
@@ -1089,6 +1110,16 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
         if (a.addend != nullptr && a.bn_bits != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 10, BK, PP>(a, stream);
         if (a.addend == nullptr && a.bn_bits == nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 4, BK, PP>(a, stream);
         return -1;
+    }
+    if constexpr (PP) {
+        // linear layers: no statistics accumulators in the kernel (EPI bit 128), single-tap form only
+        const bool plain = a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && (a.OA - 1) * a.istr < a.Hin && (a.OB - 1) * a.istr < a.Win;
+        static const bool nostats = std::getenv("PDT_GEMM_NOSTATS") == nullptr || std::atoi(std::getenv("PDT_GEMM_NOSTATS")) != 0;  // (A/B switch)
+        if (a.stats == nullptr && plain && nostats) {
+            if (a.bias != nullptr && a.addend != nullptr) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 128 | 3, BK, true, PP>(a, stream);
+            if (a.bias != nullptr) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 128 | 1, BK, true, PP>(a, stream);
+            if (a.addend == nullptr) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 128, BK, true, PP>(a, stream);
+        }
     }
     if (a.bias != nullptr && a.addend != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 3, BK, PP>(a, stream);
     if (a.bias != nullptr) return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 1, BK, PP>(a, stream);
