@@ -849,7 +849,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             stats_n0 = n0;
         }
         const int ncol = n0 + wn * TN + ech * 8;
-        const bool dense_out = p.ostr == 1 && p.oph == 0 && p.opw == 0 && p.OA == p.Hout && p.OB == p.Wout;
+        // (the statistics-free flavour is only launched for densely stored outputs: no branch on it in the row groups)
+        const bool dense_out = NOSTATS || (p.ostr == 1 && p.oph == 0 && p.opw == 0 && p.OA == p.Hout && p.OB == p.Wout);
         // Output pixels of this lane's rows in a 16-row group and the loads of the epilogue operands that share the
         // output's layout (shortcut gradient, BatchNorm inputs, pre-activation).  Two register sets: the operands of
         // group i + 1 are requested before group i is staged and processed, so their latency is covered by a whole
@@ -904,7 +905,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         for (int g = 0; g < AHEAD && g < FM; ++g) fetch(g, g % 3);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            if (p.out_nt == 3) break;  // (measurement aid: no epilogue at all, see pdt_set_out_nt_bytes)
+            if (!NOSTATS && p.out_nt == 3) break;  // (measurement aid: no epilogue at all, see pdt_set_out_nt_bytes; the
+                                                   // statistics-free flavour is not launched in measurement mode)
             if (i + AHEAD < FM) fetch(i + AHEAD, (i + AHEAD) % 3);
             size_t(&pixo)[NPS] = pixo_[i % 3];
             bool(&rok)[NPS] = rok_[i % 3];
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(yv[ps][e])));
                     }
-                    if (p.out_nt == 2) {
+                    if (!NOSTATS && p.out_nt == 2) {
                         // (measurement aid: no output store at all, see pdt_set_out_nt_bytes)
                     } else if (p.out_nt) {
                         // the empty statements keep the optimizer from merging the two branches' stores into one plain
@@ -1115,7 +1117,8 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
         // linear layers: no statistics accumulators in the kernel (EPI bit 128), single-tap form only
         const bool plain = a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && (a.OA - 1) * a.istr < a.Hin && (a.OB - 1) * a.istr < a.Win;
         static const bool nostats = std::getenv("PDT_GEMM_NOSTATS") == nullptr || std::atoi(std::getenv("PDT_GEMM_NOSTATS")) != 0;  // (A/B switch)
-        if (a.stats == nullptr && plain && nostats) {
+        const bool dense = a.ostr == 1 && a.oph == 0 && a.opw == 0 && a.OA == a.Hout && a.OB == a.Wout;
+        if (a.stats == nullptr && plain && dense && nostats && a.out_nt <= 1) {
             if (a.bias != nullptr && a.addend != nullptr) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 128 | 3, BK, true, PP>(a, stream);
             if (a.bias != nullptr) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 128 | 1, BK, true, PP>(a, stream);
             if (a.addend == nullptr) return launch_gather_gemm_ring_plain<BM, BN, WM, WN, NS, 128, BK, true, PP>(a, stream);
