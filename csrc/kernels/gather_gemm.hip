@@ -675,6 +675,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         const int ncol = stats_n0 + wn * TN + ech * 8;
         if (lane < CH && ncol < p.N) {
             float* slot = p.stats + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * p.stat_rows * p.N;
+            if (EPI & 12) {
+                // The row groups accumulate the raw moments sum(dz) and sum(dz * y); the normalised sum BatchNorm's backward
+                // wants is rstd * (sum(dz * y) - mean * sum(dz)).  Applying mean and rstd here, once per workgroup, keeps
+                // the per-channel constants out of the row groups: loaded there they cost a vmcnt(0) wait per pass, which
+                // also drained the stores of the pass before and the operands requested ahead for the next groups.
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s2[e] = (s2[e] - p.bn_consts[ncol + e] * s1[e]) * p.bn_consts[p.N + ncol + e];
+                    if (EPI & 64) s3[e] = (s3[e] - p.bn_consts2[ncol + e] * s1[e]) * p.bn_consts2[p.N + ncol + e];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 __hip_atomic_fetch_add(slot + ncol + e, s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -849,6 +860,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             stats_n0 = n0;
         }
         const int ncol = n0 + wn * TN + ech * 8;
+        float msc[8], msh[8];  // EPI & 4: scale and shift of this lane's 8 channels, for the recomputed ReLU mask
+        if constexpr ((EPI & 12) == 4) {
+            const int nc = min(ncol, p.N - 8);
+            *reinterpret_cast<f32x4*>(msc) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + nc);
+            *reinterpret_cast<f32x4*>(msc + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + nc + 4);
+            *reinterpret_cast<f32x4*>(msh) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * p.N + nc);
+            *reinterpret_cast<f32x4*>(msh + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * p.N + nc + 4);
+        }
         // (the statistics-free flavour is only launched for densely stored outputs: no branch on it in the row groups)
         const bool dense_out = NOSTATS || (p.ostr == 1 && p.oph == 0 && p.opw == 0 && p.OA == p.Hout && p.OB == p.Wout);
         // Output pixels of this lane's rows in a 16-row group and the loads of the epilogue operands that share the
@@ -971,41 +990,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                     } else if (EPI & 12) {
                         // BatchNorm-backward sums of the gradient just written (its bf16 value, as a separate pass
                         // over the stored tensor would see it)
-                        float mu[8], rs[8];
-                        *reinterpret_cast<f32x4*>(mu) = *reinterpret_cast<const f32x4*>(p.bn_consts + ncol);
-                        *reinterpret_cast<f32x4*>(mu + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + ncol + 4);
-                        *reinterpret_cast<f32x4*>(rs) = *reinterpret_cast<const f32x4*>(p.bn_consts + p.N + ncol);
-                        *reinterpret_cast<f32x4*>(rs + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + p.N + ncol + 4);
+                        // raw moments; mean and rstd are applied when the sums are flushed (see flush_stats)
                         unsigned mb = 0xffu;
                         if (EPI & 8) {
                             mb = bnb[ps];  // requested with the other operands: a load here would be waited for on the spot
                         } else {
-                            float sc[8], sh[8];
-                            *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + ncol);
-                            *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * p.N + ncol + 4);
-                            *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * p.N + ncol);
-                            *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * p.N + ncol + 4);
-                            mb = 0;
+                            mb = 0;  // ReLU mask recomputed from the BatchNorm input (scale / shift loaded once per tile)
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) mb |= ((bf16_to_f32(yv[ps][e]) * sc[e] + sh[e]) > 0.f ? 1u : 0u) << e;
+                            for (int e = 0; e < 8; ++e) mb |= ((bf16_to_f32(yv[ps][e]) * msc[e] + msh[e]) > 0.f ? 1u : 0u) << e;
                         }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float dz = ((mb >> e) & 1u) ? bf16_to_f32(v[e]) : 0.f;
                             s1[e] += dz;
-                            s2[e] += dz * (bf16_to_f32(yv[ps][e]) - mu[e]) * rs[e];
-                        }
-                        if (EPI & 64) {
-                            float mu2[8], rs2[8];
-                            *reinterpret_cast<f32x4*>(mu2) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + ncol);
-                            *reinterpret_cast<f32x4*>(mu2 + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + ncol + 4);
-                            *reinterpret_cast<f32x4*>(rs2) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + p.N + ncol);
-                            *reinterpret_cast<f32x4*>(rs2 + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts2 + p.N + ncol + 4);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float dz = ((mb >> e) & 1u) ? bf16_to_f32(v[e]) : 0.f;
-                                s3[e] += dz * (bf16_to_f32(y2v[ps][e]) - mu2[e]) * rs2[e];
-                            }
+                            s2[e] += dz * bf16_to_f32(yv[ps][e]);
+                            if (EPI & 64) s3[e] += dz * bf16_to_f32(y2v[ps][e]);
                         }
                     } else if (!NOSTATS && p.stats != nullptr) {
 #pragma unroll
