@@ -895,31 +895,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                     pixo_[st][ps] = ((static_cast<size_t>(img) * p.Hout + a * p.ostr + p.oph) * p.Wout + b * p.ostr + p.opw) * p.ldo +
                                     min(ncol, p.N - 8);
                 }
-                // operands with the layout of the output are read once: streamed past the caches when they are large
+                // Operands with the layout of the output are read once: streamed past the caches when they are large.
+                // The loads are inline assembly and their completion is awaited by hand (counted vmcnt in front of the
+                // group that uses them, see below): for compiler-issued loads the waits came out as vmcnt(0) in front
+                // of every group, which also waited for the groups requested ahead - the prefetch bought nothing.
+                // Every request issues the same number of loads (LPP per pass) whatever the run-time arguments are.
                 auto ld8 = [&](const bf16* q) {
-                    bf16x8 r;
-                    if (p.out_nt) {  // (empty statements: see the output store below)
-                        asm volatile("" ::: "memory");
-                        r = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(q));
-                        asm volatile("" ::: "memory");
-                    } else {
-                        r = *reinterpret_cast<const bf16x8*>(q);
-                    }
+                    // (no branch around the load: a value merged from two assembly statements may be copied at the merge,
+                    // before it has arrived; the streaming hint is right for read-once operands of any size)
+                    u32x4 r;
+                    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(q) : "memory");
+                    return __builtin_bit_cast(bf16x8, r);
+                };
+                auto ld1 = [&](const unsigned char* q) {
+                    unsigned r;
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(r) : "v"(q) : "memory");
                     return r;
                 };
                 if (EPI & 12) yv_[st][ps] = ld8(p.bn_y + pixo_[st][ps]);
                 if (EPI & 64) y2v_[st][ps] = ld8(p.bn_y2 + pixo_[st][ps]);
                 if (EPI & 16) yv_[st][ps] = ld8(p.act_src + pixo_[st][ps]);
-                if (EPI & 8) bnb_[st][ps] = p.bn_bits[pixo_[st][ps] >> 3];
+                if (EPI & 8) bnb_[st][ps] = ld1(p.bn_bits + (pixo_[st][ps] >> 3));
                 if (EPI & 2) {
                     av_[st][ps] = ld8(p.addend + pixo_[st][ps]);
-                    amb_[st][ps] = p.addend_bits != nullptr ? p.addend_bits[pixo_[st][ps] >> 3] : 0xffu;
+                    // (without mask bits the byte comes from the zero page and is ignored)
+                    amb_[st][ps] = ld1(p.addend_bits != nullptr ? p.addend_bits + (pixo_[st][ps] >> 3)
+                                                                : reinterpret_cast<const unsigned char*>(p.zeros));
                 }
             }
         };
         // Groups requested ahead (group g lives in register set g % 3): none with three operand tensors (they do not fit
         // the register file twice), one for the tiles whose accumulators fill half the registers, two for the smaller tiles.
         constexpr int AHEAD = (EPI & 64) ? 0 : (FM * FN <= 16 ? 2 : 1);
+        // loads one request issues per pass, and per group
+        constexpr int LPP = ((EPI & 12) ? 1 : 0) + ((EPI & 64) ? 1 : 0) + ((EPI & 16) ? 1 : 0) + ((EPI & 8) ? 1 : 0) + ((EPI & 2) ? 2 : 0);
+        constexpr int LPG = LPP * NPS;
+        static_assert(2 * LPG <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
         for (int g = 0; g < AHEAD && g < FM; ++g) fetch(g, g % 3);
 #pragma unroll
@@ -934,6 +945,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             bf16x8(&y2v)[NPS] = y2v_[i % 3];
             unsigned(&amb)[NPS] = amb_[i % 3];
             unsigned(&bnb)[NPS] = bnb_[i % 3];
+            if constexpr (LPG > 0) {
+                // The operands of this group have arrived once at most the loads of the groups requested after it are
+                // outstanding (loads return in order; younger stores only make the wait stricter).
+                const int later = min(AHEAD, FM - 1 - i);
+                if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPG) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPG) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (EPI & 2) {
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps) amb[ps] = p.addend_bits != nullptr ? amb[ps] : 0xffu;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int nl = j * 16 + (lane >> 4) * 4;
