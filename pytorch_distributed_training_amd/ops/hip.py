@@ -427,10 +427,11 @@ _TILE_WIDE = int(_os.environ.get("PDT_GEMM_TILE_WIDE", "-1"))  # -1: choose per 
 _TILE_NARROW = int(_os.environ.get("PDT_GEMM_TILE_NARROW", "-1"))  # -1: choose per shape
 _RING_MIN_TILES = int(_os.environ.get("PDT_GEMM_RING_MIN_TILES", "768"))
 # Data-gradient launches that also add a shortcut gradient and take a block tail's BatchNorm sums stream four tensors
-# through the epilogue; with the 256x256 tile's accumulators there is no register room to keep enough of those loads in
-# flight, so they run on the 256x128 tile (two groups of operands requested ahead): -1.1 ms per ResNet-50 step.  (The
-# launches that only take sums with a recomputed mask are faster on the 256x256 tile.)
-_TILE_FUSED_TAIL = int(_os.environ.get("PDT_GEMM_TILE_FUSED_TAIL", "13"))
+# through the epilogue.  They used to run on the 256x128 tile (more register room for operands requested ahead: -1.1 ms
+# per ResNet-50 step at the time); since the epilogue's loads are awaited with counted waits and its constants are out
+# of the row groups, the tile the shape rule picks is as fast or slightly faster (-0.3 % of the step), so there is no
+# special case any more (-1).  A tile id here forces that tile for these launches.
+_TILE_FUSED_TAIL = int(_os.environ.get("PDT_GEMM_TILE_FUSED_TAIL", "-1"))
 # Single-tap 256x256 launches with at least eight K-steps run on the ping-pong schedule (tile 17: the wave rows of a
 # workgroup alternate between MFMA and LDS / DMA phases): +5-15 % on linear layers (bench/pp_check.py).  Multi-tap
 # launches (3x3 convolutions) stay on tile 16: their loader's address arithmetic hides better under a wave's own MFMAs
