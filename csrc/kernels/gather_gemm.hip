@@ -817,18 +817,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 if constexpr (XF) {
                     bf16* sAx = ring + slot * STAGE;
                     const int cbase = s * BK;
+                    // A thread's chunks of a stage lie 64 rows apart (NW * 64 threads cover 64 rows of 8 chunks), so they
+                    // share the physical position and the row's swizzle: one set of constants per thread and K-step
+                    // instead of one per chunk (the table reads were four fifths of the transform's LDS traffic).
+                    static_assert((NW * 64) % 64 == 0 && BK == 64, "a thread's chunks share their channels");
+                    const int pos = tid & 7;
+                    const int cb = cbase + ((pos ^ ((tid >> 3) & 7)) << 3);  // channels of this thread's physical chunks
+                    float sc[8], sh[8];
+                    *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(xf_tab + cb);
+                    *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(xf_tab + cb + 4);
+                    *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(xf_tab + p.C + cb);
+                    *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(xf_tab + p.C + cb + 4);
 #pragma unroll
                     for (int i = 0; i < (BM * 8) / (NW * 64); ++i) {
-                        const int q = tid + i * (NW * 64);
-                        const int row = q >> 3, pos = q & 7;
-                        const int cb = cbase + ((pos ^ (row & 7)) << 3);  // channels of this physical chunk
+                        const int row = (tid >> 3) + i * ((NW * 64) >> 3);
                         bf16* a = sAx + row * BK + (pos << 3);
                         bf16x8 v = *reinterpret_cast<const bf16x8*>(a);
-                        float sc[8], sh[8];
-                        *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(xf_tab + cb);
-                        *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(xf_tab + cb + 4);
-                        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(xf_tab + p.C + cb);
-                        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(xf_tab + p.C + cb + 4);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * sc[e] + sh[e], 0.f));
                         *reinterpret_cast<bf16x8*>(a) = v;
