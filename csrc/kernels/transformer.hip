@@ -505,9 +505,36 @@ PDT_API int pdt_embedding_fwd(const long long* ids, const float* w, void* out, l
     return pdt_launch_status();
 }
 
+// Row form of the same scatter-add: a wave owns a token, its lanes walk the row with stride 64 elements, so every atomic
+// instruction covers 256 contiguous bytes of one table row (the element-vector form above spreads the 64 lanes of an
+// instruction over 64 different 32-byte segments).
+__global__ __launch_bounds__(256) void embedding_bwd_rows_kernel(const long long* __restrict__ ids, const bf16* __restrict__ g,
+                                                                float* dw, long long n, int D, long long vocab) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = static_cast<long long>(gridDim.x) * 4;
+    for (long long i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < n; i += waves) {
+        const long long id = ids[i];
+        if (id < 0 || id >= vocab) continue;
+        const bf16* src = g + i * D;
+        float* dst = dw + id * D;
+        for (int c = lane * 2; c < D; c += 128) {
+            const bf16x2 v = *reinterpret_cast<const bf16x2*>(src + c);
+            __hip_atomic_fetch_add(dst + c, bf16_to_f32(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dst + c + 1, bf16_to_f32(v[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 PDT_API int pdt_embedding_bwd(const long long* ids, const void* g, float* dw, long long n, int D, long long vocab,
                               void* stream) {
     if (n <= 0 || D <= 0 || (D % 8) != 0 || vocab <= 0) return -1;
+    static const bool rows = std::getenv("PDT_EMB_BWD_ROWS") == nullptr || std::atoi(std::getenv("PDT_EMB_BWD_ROWS")) != 0;
+    if (rows) {
+        const long long blocks = (n + 3) / 4;
+        hipLaunchKernelGGL(embedding_bwd_rows_kernel, dim3(static_cast<unsigned>(blocks < 16384 ? blocks : 16384)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), ids, static_cast<const bf16*>(g), dw, n, D, vocab);
+        return pdt_launch_status();
+    }
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_grid8(n * (D / 8))), dim3(256), 0, static_cast<hipStream_t>(stream), ids,
                        static_cast<const bf16*>(g), dw, n, D, vocab);
     return pdt_launch_status();
