@@ -504,8 +504,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
     };
     // pieces [a_lo, a_hi) of the A tile and [b_lo, b_hi) of the B tile of the stage under the cursor
+    // The tap under the cursor, read from the argument block when the cursor moves onto it - a K-step (ping-pong: a phase)
+    // before its first use - instead of inside the issue sequence, where the scalar loads' latency sat in front of the
+    // DMA requests of every K-step.
+    int ld_dh = p.tap_dh[0], ld_dw = p.tap_dw[0], ld_wo = p.tap_woff[0];
     auto issue_pieces = [&](int a_lo, int a_hi, int b_lo, int b_hi) {
-        const int dh = p.tap_dh[ld_t], dw = p.tap_dw[ld_t], woff = p.tap_woff[ld_t] + ld_c0 + kchunk;
+        const int dh = ld_dh, dw = ld_dw, woff = ld_wo + ld_c0 + kchunk;
         bf16* sA = ring + ld_slot * STAGE;
         bf16* sB = sA + BM * BK;
 #pragma unroll
@@ -541,6 +545,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 ld_tile += G;
                 loader_tile(ld_tile);
             }
+            ld_dh = p.tap_dh[ld_t];
+            ld_dw = p.tap_dw[ld_t];
+            ld_wo = p.tap_woff[ld_t];
         }
     };
 
