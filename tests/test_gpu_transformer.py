@@ -70,18 +70,20 @@ def test_gelu_and_bias_residual(ht):
     assert _rel(bias.grad, g.float().sum(0)) < 1e-3
 
 
-def test_embedding(ht):
+@pytest.mark.parametrize("d,rows", [(64, (4, 9)), (200, (3, 50)), (1024, (8, 300))])
+def test_embedding(ht, d, rows):
+    """Gather forward; scatter-add backward (a wave per token row) with many tokens hitting the same table rows."""
     torch.manual_seed(2)
     dev = _dev()
-    w = torch.randn(100, 64, device=dev).requires_grad_(True)
-    ids = torch.randint(0, 100, (4, 9), device=dev)
+    w = torch.randn(100, d, device=dev).requires_grad_(True)
+    ids = torch.randint(0, 100, rows, device=dev)
     out = ht.embedding(ids, w)
-    assert out.shape == (4, 9, 64)
+    assert out.shape == (*rows, d)
     assert torch.equal(out, w.detach()[ids].to(torch.bfloat16))
-    g = torch.randn(4, 9, 64, device=dev).to(torch.bfloat16)
+    g = torch.randn(*rows, d, device=dev).to(torch.bfloat16)
     out.backward(g)
     ref = torch.zeros_like(w)
-    ref.index_put_((ids.reshape(-1),), g.float().reshape(-1, 64), accumulate=True)
+    ref.index_put_((ids.reshape(-1),), g.float().reshape(-1, d), accumulate=True)
     assert _rel(w.grad, ref) < 1e-5
 
 
