@@ -48,6 +48,7 @@ namespace {
 // usually read from the main thread.
 std::mutex g_err_mu;
 std::string g_last_error;
+std::atomic<int> g_live_streams{0};  // HIP streams created by this library and not yet destroyed
 
 void set_error(const std::string& s) {
     std::lock_guard<std::mutex> g(g_err_mu);
@@ -71,11 +72,12 @@ ncclDataType_t to_nccl_dtype(int dtype) {
         case 0: return ncclFloat32;
         case 1: return ncclBfloat16;
         case 2: return ncclFloat16;
+        case 3: return ncclFloat64;
         default: return ncclFloat32;
     }
 }
 
-size_t dtype_bytes(int dtype) { return dtype == 0 ? 4 : 2; }
+size_t dtype_bytes(int dtype) { return dtype == 0 ? 4 : (dtype == 3 ? 8 : 2); }
 
 // fp32 -> bf16 with a scale (1 / world size); 8 elements per thread, n is a multiple of 8
 __global__ void pack_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n8, float scale) {
@@ -291,10 +293,12 @@ PdtComm* pdt_rccl_comm_create(const char* id_bytes, int rank, int world, int dev
         delete c;
         return nullptr;
     }
+    g_live_streams++;
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     if (!nccl_ok(ncclCommInitRank(&c->comm, world, id, rank), "ncclCommInitRank")) {
         (void)hipStreamDestroy(c->stream);
+        g_live_streams--;
         delete c;
         return nullptr;
     }
@@ -309,9 +313,15 @@ void pdt_rccl_comm_destroy(PdtComm* c) {
     }
     if (c->fence_in) (void)hipEventDestroy(c->fence_in);
     if (c->fence_out) (void)hipEventDestroy(c->fence_out);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) {
+        (void)hipStreamDestroy(c->stream);
+        g_live_streams--;
+    }
     delete c;
 }
+
+// HIP streams this library currently owns (one per live communicator): part of the process's stream census.
+int pdt_rccl_live_streams() { return g_live_streams.load(); }
 
 void* pdt_rccl_comm_stream(PdtComm* c) { return c->stream; }
 
@@ -358,7 +368,7 @@ int pdt_rccl_broadcast(PdtComm* c, void* buf, int64_t bytes, int root, void* str
 
 // Collectives on the communication stream, ordered after everything already submitted to `step_stream` and before
 // everything submitted to it afterwards (two event edges, no host synchronisation; recordable into a hipGraph).
-// kind: 0 broadcast of `count` bytes from `root`, 1 all-reduce sum, 2 all-reduce mean, 3 all-reduce max.
+// kind: 0 broadcast of `count` bytes from `root`, 1 all-reduce sum, 2 all-reduce mean, 3 all-reduce max, 4 min.
 int pdt_rccl_ordered(PdtComm* c, int kind, void* buf, int64_t count, int dtype, int root, void* step_stream) {
     auto step = static_cast<hipStream_t>(step_stream);
     if (!hip_ok(hipEventRecord(c->fence_in, step), "hipEventRecord(fence_in)") ||
@@ -368,7 +378,7 @@ int pdt_rccl_ordered(PdtComm* c, int kind, void* buf, int64_t count, int dtype, 
     if (kind == 0) {
         ok = nccl_ok(ncclBroadcast(buf, buf, static_cast<size_t>(count), ncclInt8, root, c->comm, c->stream), "ncclBroadcast");
     } else {
-        const ncclRedOp_t op = kind == 1 ? ncclSum : (kind == 2 ? ncclAvg : ncclMax);
+        const ncclRedOp_t op = kind == 1 ? ncclSum : (kind == 2 ? ncclAvg : (kind == 4 ? ncclMin : ncclMax));
         ok = nccl_ok(ncclAllReduce(buf, buf, static_cast<size_t>(count), to_nccl_dtype(dtype), op, c->comm, c->stream),
                      "ncclAllReduce");
     }

@@ -47,9 +47,15 @@ from .train import TrainConfig, run_training
 @click.option("--eval", "evaluate", is_flag=True, default=False, help="run the evaluation loop after training")
 @click.option("--checkpoint-path", type=str, default="", help="rank 0 writes model.state_dict() here")
 @click.option("--resume", type=str, default="",
-              help="checkpoint to restore before training; 'auto': --checkpoint-path when it exists (restartable job lines)")
+              help="checkpoint to restore before training; 'auto': the newest intact checkpoint at --checkpoint-path, "
+                   "if any (restartable job lines)")
 @click.option("--save-every", type=int, default=0, help="also checkpoint every N steps")
-@click.option("--bucket-mb", type=float, default=25.0, show_default=True, help="gradient bucket capacity")
+@click.option("--keep-checkpoints", type=int, default=2, show_default=True,
+              help="checkpoint generations (<path>.step<N>) kept next to --checkpoint-path; when the newest one is torn "
+                   "(the job died while writing it) a resume falls back to the one before; 0: overwrite in place")
+@click.option("--bucket-mb", type=str, default="auto", show_default=True,
+              help="gradient bucket capacity in MiB, or 'auto': chosen after the first step from the all-reduce latency and "
+                   "bandwidth measured on this node and the measured gradient-ready times (nothing to tune on one rank)")
 @click.option("--first-bucket-mb", type=float, default=1.0, show_default=True)
 @click.option("--sync-buffers/--no-sync-buffers", default=True, help="broadcast BatchNorm buffers from rank 0 every step")
 @click.option("--last-bucket-mb", type=float, default=1.0, show_default=True,
@@ -71,7 +77,9 @@ from .train import TrainConfig, run_training
 @click.option("--stop-check-every", type=int, default=0,
               help="steps between the ranks' agreements on stop requests (0: every step on CPU, every 16 on GPU)")
 @click.option("--profile", type=str, default="", help="write a chrome trace of host-side phases to this path")
-@click.option("--check-finite", is_flag=True, default=False)
+@click.option("--check-finite", is_flag=True, default=False,
+              help="stop with an error on a non-finite loss (checked on --log-every steps; distributed GPU jobs act on it "
+                   "at the next agreement step, at most --stop-check-every steps later, and once more when the loop ends)")
 @click.option("--hip-graph/--no-hip-graph", default=None,
               help="record the whole training step into a hipGraph after --graph-after eager steps (launch-bound configs); "
                    "default: automatic - on for single-GPU image runs of at most 64 x 224 x 224 input pixels per batch")

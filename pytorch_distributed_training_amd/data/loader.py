@@ -62,8 +62,11 @@ class BatchLoader:
     ``num_workers`` threads (at least one) each gather a batch into a buffer taken from a ring of pinned host
     tensors; batches are delivered in sampler order.  The gather is a single ``index_select`` (it releases the
     interpreter lock), so a handful of threads saturates host memory bandwidth where per-item loading would need
-    dozens of processes.  A buffer returns to the ring when the batch after the next one is requested, i.e. after
-    the consumer has had a full iteration to finish its (asynchronous) upload."""
+    dozens of processes.  A worker takes a buffer first and a batch number second, so whoever holds a batch number
+    can always fill it (numbers handed out in order + buffers handed out before numbers = no batch can starve behind
+    later ones).  A buffer returns to the ring when the batch after the next one is requested; if the consumer
+    registered an upload event for it (:meth:`note_upload`, the prefetcher does), that event is awaited first, so
+    a pinned buffer is never refilled while its host-to-device copy could still be reading it."""
 
     def __init__(self, dataset, batch_size: int, sampler, num_workers: int = 2, drop_last: bool = False,
                  pin_memory: bool = False):
@@ -72,6 +75,18 @@ class BatchLoader:
         self.drop_last = drop_last
         self.pin = bool(pin_memory) and torch.cuda.is_available()
         self._ring: List[torch.Tensor] = []
+        self._uploads = {}  # storage address of a ring buffer -> event recorded behind its latest upload
+
+    def note_upload(self, host_tensor: torch.Tensor, event) -> None:
+        """The consumer started an asynchronous copy out of ``host_tensor`` (a batch this loader yielded) and
+        ``event`` completes when the copy has."""
+        self._uploads[host_tensor.untyped_storage().data_ptr()] = event
+
+    def _release(self, free: "queue.Queue", buf: torch.Tensor) -> None:
+        ev = self._uploads.pop(buf.untyped_storage().data_ptr(), None)
+        if ev is not None:
+            ev.synchronize()  # long done in practice: two batches were fetched since
+        free.put(buf)
 
     def __len__(self) -> int:
         n = len(self.sampler)
@@ -105,12 +120,16 @@ class BatchLoader:
 
         def work():
             while not stop.is_set():
+                buf = free.get()  # the buffer first: a batch number is only ever held together with a buffer
                 try:
                     k, s0 = todo.get_nowait()
                 except queue.Empty:
+                    free.put(buf)
+                    return
+                if stop.is_set():
+                    free.put(buf)
                     return
                 sel = idx[s0:s0 + bs]
-                buf = free.get()
                 try:
                     out = buf if len(sel) == bs else buf[: len(sel)]
                     imgs, labels = self.dataset.get_batch(sel, out=out)
@@ -136,12 +155,12 @@ class BatchLoader:
                     raise errors[0]
                 held.append(buf)
                 if len(held) > 2:
-                    free.put(held.pop(0))
+                    self._release(free, held.pop(0))
                 yield imgs, labels
         finally:
             stop.set()
             for b in held:
-                free.put(b)
+                self._release(free, b)
             for _ in threads:  # unblock workers waiting for a buffer
                 free.put(self._ring[0])
             for t in threads:
@@ -168,6 +187,11 @@ class DevicePrefetcher:
             return (self.convert(out[0]),) + out[1:] if (self.convert and out[0].dtype == torch.uint8) else out
         with torch.cuda.stream(self.stream):
             out = tuple(t.to(self.device, non_blocking=True) for t in batch)
+            note = getattr(self.loader, "note_upload", None)
+            if note is not None and isinstance(batch[0], torch.Tensor) and batch[0].device.type == "cpu":
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                note(batch[0], ev)  # the loader's pinned buffer may be refilled once this copy is through
             if self.convert is not None and out[0].dtype == torch.uint8:
                 raw = out[0]
                 out = (self.convert(raw),) + out[1:]

@@ -43,6 +43,15 @@ class ShardedSampler(Sampler[int]):
             self.num_samples = math.ceil(self.n / num_replicas)  # padded by wrapping around
         self.total_size = self.num_samples * num_replicas
 
+    @property
+    def valid_samples(self) -> int:
+        """How many leading samples of this rank's shard are not wrap-around padding.  Shard position ``j`` is global
+        position ``rank + j * num_replicas``; positions from ``n`` on repeat earlier samples.  (An evaluation that
+        counts every sample once stops there.)"""
+        if self.rank >= self.n:
+            return 0
+        return min(self.num_samples, (self.n - self.rank + self.num_replicas - 1) // self.num_replicas)
+
     def set_epoch(self, epoch: int) -> None:
         """Change the permutation; call once per epoch with the same value on every rank."""
         self.epoch = int(epoch)

@@ -144,6 +144,7 @@ def rccl() -> ctypes.CDLL:
         lib.pdt_rccl_buckets_wire_bytes.restype = ctypes.c_int64
         lib.pdt_rccl_buckets_device_count.argtypes = [ctypes.c_void_p]
         lib.pdt_rccl_buckets_device_count.restype = ctypes.c_int64
+        lib.pdt_rccl_live_streams.restype = ctypes.c_int
         lib.pdt_rccl_launch_fn.restype = ctypes.c_void_p
         lib.pdt_rccl_wait_fn.restype = ctypes.c_void_p
         _rccl = lib

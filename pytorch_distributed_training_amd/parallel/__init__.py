@@ -4,7 +4,16 @@ from __future__ import annotations
 
 import torch
 
-from .env import DistEnv, barrier, init_distributed, select_backend, shutdown  # noqa: F401
+from .env import (  # noqa: F401
+    DistEnv,
+    all_gather_values,
+    all_reduce_values,
+    barrier,
+    init_distributed,
+    select_backend,
+    shutdown,
+)
+from .env import _comm_store
 from .reducer import BucketedDataParallel, BucketPlan, GradReducer, plan_buckets  # noqa: F401
 from .transport import (  # noqa: F401
     LoopbackFabric,
@@ -33,7 +42,10 @@ def make_transport(env: DistEnv, grad_dtype: str = "fp32", algorithm: str = "all
         raise ValueError(f"grad_dtype must be one of {sorted(WIRE_DTYPES)}")
     wire = WIRE_DTYPES[grad_dtype]
     if env.backend == "nccl":
-        return RcclTransport(RcclComm(env.rank, env.world_size, env.device), wire_dtype=wire, algorithm=algorithm)
+        if env.comm is None:  # an environment that was not built by init_distributed
+            env.comm = RcclComm(env.rank, env.world_size, env.device, store=_comm_store(env))
+        # the process's one communicator: bucket collectives share it (and its stream) with the control collectives
+        return RcclTransport(env.comm, wire_dtype=wire, algorithm=algorithm)
     if algorithm != "allreduce":
         raise ValueError("the reduce-scatter + all-gather form needs the RCCL transport (GPU ranks)")
     return TorchDistTransport(wire_dtype=wire)

@@ -16,6 +16,15 @@ Deliberate differences from the reference:
   it) so the plumbing can be exercised without GPUs;
 * a missing ``WORLD_SIZE`` raises a readable error instead of ``KeyError``
   (main.py:38), and the group is destroyed on exit (the reference never does).
+
+One communicator and no hidden streams on a GPU rank.  The data plane of a GPU rank is this
+package's own RCCL communicator (``DistEnv.comm``: gradient buckets, buffer and parameter
+broadcasts, stop agreement, barriers, evaluation sums) on its one communication stream.
+``torch.distributed`` is brought up on *gloo* there: it keeps rendezvous, rank bookkeeping and host
+object exchange working without ever creating a second RCCL communicator or a stream of its own
+(the box serves four hardware queues per process; step, copy and communication stream plus a
+graph-capture stream are the whole budget).  ``DistEnv.backend`` still reads ``nccl`` for such a
+rank - the backend the reference selects at main.py:40 - and ``control_backend`` says ``gloo``.
 """
 
 from __future__ import annotations
@@ -23,7 +32,7 @@ from __future__ import annotations
 import datetime
 import os
 from dataclasses import dataclass
-from typing import Optional
+from typing import Any, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -39,6 +48,9 @@ class DistEnv:
     backend: Optional[str] = None  # None => single process, no group
     device: torch.device = torch.device("cpu")
     owns_group: bool = False
+    control_backend: Optional[str] = None  # what torch.distributed itself runs on (gloo, also on GPU ranks)
+    comm: Any = None  # RcclComm of a GPU rank: the only communicator of the process
+    store: Any = None  # the rendezvous key-value store (scoped to this incarnation of the job)
 
     @property
     def distributed(self) -> bool:
@@ -69,7 +81,10 @@ def resolve_local_rank(rank: int) -> int:
 
 
 def init_distributed(distributed: bool, use_cpu: bool = False, timeout_s: float = 600.0) -> DistEnv:
-    """Create the default process group (when ``distributed``) and pick this rank's device."""
+    """Create the default process group (when ``distributed``) and pick this rank's device.
+
+    GPU ranks: torch's group runs on gloo (host control plane) and this package's RCCL communicator is created
+    here, once, from the same store; every device collective of the process goes through it."""
     gpu_ok = torch.cuda.is_available() and not use_cpu
     if not distributed:
         device = torch.device("cuda", torch.cuda.current_device()) if gpu_ok else torch.device("cpu")
@@ -86,6 +101,8 @@ def init_distributed(distributed: bool, use_cpu: bool = False, timeout_s: float 
     rank = int(os.environ["RANK"])
     if world_size < 1:
         raise RuntimeError(f"WORLD_SIZE must be >= 1, got {world_size}")
+    if not 0 <= rank < world_size:
+        raise RuntimeError(f"RANK must be in [0, {world_size}), got {rank}")
     local_rank = resolve_local_rank(rank)
     backend = select_backend(use_cpu)
     if backend == "nccl":
@@ -97,59 +114,137 @@ def init_distributed(distributed: bool, use_cpu: bool = False, timeout_s: float 
     else:
         device = torch.device("cpu")
 
-    if backend == "nccl" and os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
-        # a one-node job that meets on the loopback address: let RCCL bootstrap over the loopback interface too,
-        # whatever other interfaces the box has (a container hostname that does not resolve, a NIC without a route)
+    if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+        # a one-node job that meets on the loopback address: let RCCL and gloo bootstrap over the loopback interface
+        # too, whatever other interfaces the box has (a container hostname that does not resolve, a NIC without a route)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     owns = False
+    store = None
     if not dist.is_initialized():
-        kwargs = dict(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
-        if backend == "nccl":
-            kwargs["device_id"] = device  # eager communicator bound to this rank's GPU
-        store = _restart_scoped_store(world_size, timeout_s)
+        store = _rendezvous_store(rank, world_size, timeout_s)
+        kwargs = dict(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
         if store is not None:
-            kwargs.update(store=store, rank=rank, world_size=world_size)
+            kwargs.update(store=dist.PrefixStore("c10d", store), rank=rank, world_size=world_size)
         dist.init_process_group(**kwargs)
         owns = True
     set_rank(dist.get_rank())
-    return DistEnv(
+    env = DistEnv(
         rank=dist.get_rank(),
         local_rank=local_rank,
         world_size=dist.get_world_size(),
         backend=backend,
         device=device,
         owns_group=owns,
+        control_backend=dist.get_backend(),
+        store=store,
     )
+    if backend == "nccl":
+        from .transport import RcclComm
+
+        env.comm = RcclComm(env.rank, env.world_size, device, store=_comm_store(env))
+    return env
 
 
-def _restart_scoped_store(world_size: int, timeout_s: float):
-    """Under a launcher that restarts failed worker groups (``torchrun --max-restarts``) with a fixed
-    ``--master-addr/--master-port``, the launcher's key-value store outlives the workers: the addresses the previous
+def _rendezvous_store(rank: int, world_size: int, timeout_s: float):
+    """The key-value store of this job, created explicitly (the group and the RCCL bootstrap both use it, and no
+    private accessor of torch is needed to get at it afterwards).
+
+    Under a launcher that restarts failed worker groups (``torchrun --max-restarts``) with a fixed
+    ``--master-addr/--master-port``, the launcher's store outlives the workers: the addresses the previous
     incarnation published are still in it, and a restarted rank that reads one before its peer has overwritten it
-    connects to a process that no longer exists.  Scope every key of this incarnation by the restart count.
-    Returns ``None`` when the process was not started by such a launcher (plain ``env://`` initialisation)."""
-    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") != "True" or "TORCHELASTIC_RESTART_COUNT" not in os.environ:
-        return None
+    connects to a process that no longer exists.  Every key of this incarnation is therefore scoped by the restart
+    count.  Without such a launcher rank 0 hosts the store on ``MASTER_PORT``.  Returns ``None`` when the address
+    is not in the environment (torch's own ``env://`` handling then reports what is missing)."""
     if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
         return None
-    base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world_size, is_master=False,
-                         timeout=datetime.timedelta(seconds=timeout_s))
-    return dist.PrefixStore(f"/pdt/attempt_{os.environ['TORCHELASTIC_RESTART_COUNT']}", base)
+    addr, port = os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"])
+    timeout = datetime.timedelta(seconds=timeout_s)
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+        base = dist.TCPStore(addr, port, world_size, is_master=False, timeout=timeout)
+        return dist.PrefixStore(f"/pdt/attempt_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}", base)
+    return dist.TCPStore(addr, port, world_size, is_master=(rank == 0), timeout=timeout, wait_for_workers=False)
+
+
+_comm_serial = 0
+
+
+def _comm_store(env: DistEnv):
+    """Store the RCCL unique id travels through: the job's own store when this module created it, else (a group
+    initialised by the caller) a host broadcast through that group."""
+    global _comm_serial
+    _comm_serial += 1
+    if env.store is not None:
+        return dist.PrefixStore(f"pdt/rccl/{_comm_serial}", env.store)
+    return _GroupStore()
+
+
+class _GroupStore:
+    """``set`` / ``get`` of one value from rank 0 through the default group's object broadcast (for process groups
+    that were created outside this module, whose store is not ours to use)."""
+
+    def __init__(self):
+        self._value = None
+
+    def set(self, _key, value):
+        self._value = value
+        dist.broadcast_object_list([bytes(value)], src=0)
+
+    def get(self, _key):
+        box = [None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
 
 def barrier(env: DistEnv) -> None:
-    if env.distributed and dist.is_initialized():
-        if env.backend == "nccl":
-            dist.barrier(device_ids=[env.device.index])
-        else:
-            dist.barrier()
+    """Every rank has reached this point (host-level).  GPU ranks: a one-element all-reduce on the RCCL communicator
+    behind everything already submitted to the current stream, then a wait for that stream - no other communicator
+    or stream is involved."""
+    if not (env.distributed and dist.is_initialized()):
+        return
+    if env.comm is not None:
+        t = torch.zeros(1, dtype=torch.float32, device=env.device)
+        env.comm.ordered_all_reduce_(t, "sum")
+        torch.cuda.current_stream(env.device).synchronize()
+    else:
+        dist.barrier()
+
+
+def all_reduce_values(env: DistEnv, values: Sequence[float], op: str = "sum") -> List[float]:
+    """Host numbers reduced over ranks (``sum`` | ``max`` | ``min``) in double precision; every rank gets the result.
+    Control-plane use only (stop flags, evaluation totals, benchmark timings): GPU ranks go through the RCCL
+    communicator, CPU ranks through gloo."""
+    vals = [float(v) for v in values]
+    if not (env.distributed and dist.is_initialized()) or env.world_size == 1:
+        return vals
+    sign = -1.0 if op == "min" else 1.0
+    kind = "sum" if op == "sum" else "max"
+    if env.comm is not None:
+        t = torch.tensor([sign * v for v in vals], dtype=torch.float64, device=env.device)
+        env.comm.ordered_all_reduce_(t, kind)
+        out = t.cpu().tolist()
+    else:
+        t = torch.tensor([sign * v for v in vals], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX)
+        out = t.tolist()
+    return [sign * v for v in out]
+
+
+def all_gather_values(env: DistEnv, value: float) -> List[float]:
+    """One number from every rank, in rank order, on every rank."""
+    slots = [0.0] * max(env.world_size, 1)
+    slots[env.rank] = float(value)
+    return all_reduce_values(env, slots, "sum")
 
 
 def shutdown(env: DistEnv) -> None:
-    """Barrier, then destroy the group this module created."""
+    """Barrier, close the RCCL communicator, then destroy the group this module created."""
     if env.distributed and dist.is_initialized():
         try:
             barrier(env)
         finally:
+            if env.comm is not None:
+                env.comm.close()
+                env.comm = None
             if env.owns_group:
                 dist.destroy_process_group()

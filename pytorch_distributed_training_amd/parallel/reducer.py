@@ -338,8 +338,6 @@ class BucketedDataParallel(nn.Module):
     rank-0 checkpoint loads straight into an unwrapped model.
     """
 
-    _verify_round = 0
-
     def __init__(
         self,
         module: nn.Module,
@@ -374,22 +372,15 @@ class BucketedDataParallel(nn.Module):
 
     # -- construction-time collectives
     def _verify_shapes(self) -> None:
+        """Every rank holds the same parameter names, shapes and dtypes (a host-side exchange of digests through
+        the control group: no device collective, nothing that needs a second communicator)."""
+        if _is_loopback(self.transport) or not (dist.is_available() and dist.is_initialized()):
+            return
         digest = params_digest(self.module)
-        if self._use_dist:
-            digests: List[Optional[str]] = [None] * dist.get_world_size(self._group)
-            dist.all_gather_object(digests, digest, group=self._group)
-            if any(d != digests[0] for d in digests):
-                raise RuntimeError(f"parameter names/shapes differ across ranks: {digests}")
-        elif dist.is_available() and dist.is_initialized() and not _is_loopback(self.transport):
-            # host-side check through the rendezvous store: no device collective, no second communicator involved
-            store = dist.distributed_c10d._get_default_store()
-            BucketedDataParallel._verify_round += 1
-            prefix = f"pdt/param_digest/{BucketedDataParallel._verify_round}"
-            rank, world = dist.get_rank(), dist.get_world_size()
-            store.set(f"{prefix}/{rank}", digest)
-            digests = [store.get(f"{prefix}/{r}").decode() for r in range(world)]
-            if any(d != digests[0] for d in digests):
-                raise RuntimeError(f"parameter names/shapes differ across ranks: {digests}")
+        digests: List[Optional[str]] = [None] * dist.get_world_size(self._group)
+        dist.all_gather_object(digests, digest, group=self._group)
+        if any(d != digests[0] for d in digests):
+            raise RuntimeError(f"parameter names/shapes differ across ranks: {digests}")
 
     def _bcast(self, t: torch.Tensor) -> None:
         if self._use_dist:

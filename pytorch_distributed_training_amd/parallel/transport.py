@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from .. import native
 
-DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.float64: 3}
 
 
 class Transport:
@@ -208,7 +208,8 @@ class RcclComm:
         RcclComm._counter += 1
         if world_size > 1:
             if store is None:
-                store = dist.distributed_c10d._get_default_store()
+                raise ValueError("a multi-rank RCCL communicator needs a key-value store (set/get) that every rank "
+                                 "can reach, to hand out rank 0's unique id")
             if rank == 0:
                 buf = ctypes.create_string_buffer(nbytes)
                 self._check(self._lib.pdt_rccl_unique_id(buf), "ncclGetUniqueId")
@@ -268,7 +269,7 @@ class RcclComm:
 
     def ordered_all_reduce_(self, tensor: torch.Tensor, op: str = "sum") -> None:
         assert tensor.is_cuda and tensor.is_contiguous()
-        kind = {"sum": 1, "mean": 2, "max": 3}[op]
+        kind = {"sum": 1, "mean": 2, "max": 3, "min": 4}[op]
         self._check(
             self._lib.pdt_rccl_ordered(self._h, kind, tensor.data_ptr(), tensor.numel(), DTYPE_CODE[tensor.dtype], 0,
                                        current_stream_handle(self.device)),

@@ -31,9 +31,11 @@ from ..data import (
 )
 from ..models import MODELS, build_model
 from ..optim import build_optimizer
-from ..parallel import DistEnv, barrier, init_distributed, shutdown, wrap_data_parallel
+from ..parallel.autotune import BucketAutoTuner
+from ..parallel import DistEnv, all_reduce_values, barrier, init_distributed, shutdown, wrap_data_parallel
 from ..utils.logging import get_logger, rank_zero_print
 from ..utils.meter import AverageMeter, ThroughputMeter
+from ..utils.streams import check_stream_budget, install_stream_census
 from ..utils.timers import ChromeTrace, StepTimer
 from ..utils.watchdog import GracefulStop, StepWatchdog, maybe_inject_fault
 from . import checkpoint as ckpt
@@ -71,7 +73,10 @@ class TrainConfig:
     checkpoint_path: str = ""
     resume: str = ""  # checkpoint to restore; "auto": --checkpoint-path when it exists (restartable job lines)
     save_every: int = 0  # steps; 0 => only at the end
-    bucket_mb: float = 25.0
+    keep_checkpoints: int = 2  # checkpoint generations kept on disk; a torn newest one falls back to the one before
+    # gradient bucket capacity in MiB, or "auto": chosen after the first step from the measured all-reduce cost of
+    # this node and the measured gradient-ready times of this model (single rank: nothing to tune, 25 MiB)
+    bucket_mb: Any = "auto"
     first_bucket_mb: float = 1.0
     last_bucket_mb: float = 1.0
     grad_dtype: str = "fp32"  # element type of gradients on the wire: fp32 | bf16
@@ -130,6 +135,7 @@ class Trainer:
     def __init__(self, cfg: TrainConfig, env: Optional[DistEnv] = None):
         self.cfg = cfg
         self._owns_env = env is None
+        install_stream_census()
         self.env = env if env is not None else init_distributed(cfg.distributed, cfg.use_cpu, cfg.dist_timeout_s)
         if self.env.distributed:
             # contract line 1 (main.py:42)
@@ -160,13 +166,16 @@ class Trainer:
             model = model.to(memory_format=torch.channels_last)
         self.raw_model = ops.prepare_module(model)
         self._use_graph = self._decide_graph()
+        self._auto_buckets = False
         if self.env.distributed:
+            self._auto_buckets = str(cfg.bucket_mb).lower() == "auto"
             model = wrap_data_parallel(
-                model, self.env, cfg.bucket_mb, cfg.first_bucket_mb,
+                model, self.env, 25.0 if self._auto_buckets else float(cfg.bucket_mb), cfg.first_bucket_mb,
                 cfg.sync_buffers and not self._use_graph,  # the per-step buffer broadcast is not part of a recorded step
                 cfg.grad_dtype, cfg.reduce_algorithm, cfg.last_bucket_mb,
             )
         self.model = model
+        self.bucket_decision = None  # what --bucket-mb auto chose (None: fixed capacity, or a single rank)
         # contract line 2 (main.py:59)
         print(f"Device - {self.env.device_label}", flush=True)
 
@@ -177,19 +186,26 @@ class Trainer:
         self.start_epoch = 0
         self.global_step = 0
         self.start_batch = 0  # micro-batches of ``start_epoch`` already consumed before the checkpoint was written
-        resume = cfg.resume
+        self._saved_batches_per_epoch = 0  # length of an epoch in the run that wrote the checkpoint (0: unknown)
+        resume = asked = cfg.resume
         if resume == "auto":
-            resume = cfg.checkpoint_path if (cfg.checkpoint_path and os.path.exists(cfg.checkpoint_path)) else ""
+            asked = cfg.checkpoint_path
+            # the newest checkpoint that is whole: the main pair, or - when the job died while replacing it - the
+            # generation before it
+            resume = (ckpt.find_resumable(cfg.checkpoint_path) or "") if cfg.checkpoint_path else ""
         if resume:
             info = ckpt.load_checkpoint(resume, self.model, self.optimizer)
             self.start_epoch, self.global_step = info["epoch"], info["step"]
             self.start_batch = int(info.get("extra", {}).get("batch_in_epoch", 0))
+            self._saved_batches_per_epoch = int(info.get("extra", {}).get("batches_per_epoch", 0))
             # the saved generator state is rank 0's; giving it to every rank would make their random streams equal
             if info.get("torch_rng") is not None and self.env.rank == 0:
                 torch.set_rng_state(info["torch_rng"])
             elif self.env.rank != 0:
                 torch.manual_seed(cfg.seed + 1_000_003 * self.env.rank + self.global_step)
-            rank_zero_print(f"Resumed from {resume} at epoch {self.start_epoch}, step {self.global_step}"
+            if info["source"] != asked:
+                rank_zero_print(f"Checkpoint {asked} is torn or missing; using the intact generation {info['source']}")
+            rank_zero_print(f"Resumed from {info['source']} at epoch {self.start_epoch}, step {self.global_step}"
                             + (f", batch {self.start_batch} of the epoch" if self.start_batch else ""))
         self.timer = StepTimer(self.device, enabled=bool(cfg.profile))
         self.trace = ChromeTrace(self.env.rank) if cfg.profile else None
@@ -351,10 +367,16 @@ class Trainer:
         self.model.train()
         self._zero_grad()
         self.stopper.install()
+        if self.device.type == "cuda":
+            self.stream_census = check_stream_budget(f"rank {env.rank}")
         dog = StepWatchdog(cfg.watchdog_s, env.rank, probe=self._comm_probe(), probe_every_s=cfg.comm_poll_s,
                            before_exit=self._abort_comm).start()
         check_every = cfg.stop_check_every or (1 if self.device.type == "cpu" else 16)
         ga = max(1, cfg.grad_accum)
+        tuner = BucketAutoTuner(self.model, env, cfg.grad_dtype) if self._auto_buckets else None
+        if tuner is not None and not tuner.active:
+            tuner = None
+        tuner_armed = False
 
         if os.environ.get("PDT_TEST_PIDFILE_RANK1") and env.rank == 1:  # lets a test signal exactly this rank
             with open(os.environ["PDT_TEST_PIDFILE_RANK1"], "w") as f:
@@ -372,6 +394,9 @@ class Trainer:
         try:
             if cfg.steps and self.global_step >= cfg.steps:
                 done = True
+            if self.start_batch and self.start_batch == len(loader):
+                # a checkpoint of an older format taken on the last batch of an epoch: that epoch is finished
+                self.start_epoch, self.start_batch = self.start_epoch + 1, 0
             for epoch in range(self.start_epoch, cfg.epochs):
                 if done:
                     break
@@ -382,6 +407,12 @@ class Trainer:
                 n_batches = len(loader)
                 if skip:
                     if skip >= n_batches:
+                        # the position does not exist in this run's epochs: batch size, world size or dataset length
+                        # changed since the checkpoint was written (a checkpoint taken on the last batch of an epoch
+                        # is recorded as the start of the next one)
+                        rank_zero_print(f"Resume position batch {skip} is beyond this run's {n_batches} batches per "
+                                        f"epoch (the checkpoint's run had {self._saved_batches_per_epoch or 'an unknown number'}); "
+                                        f"epoch {epoch} starts from its first batch")
                         skip = 0
                     elif sampler is not None:
                         sampler.set_start(skip * cfg.batch_size)
@@ -398,9 +429,18 @@ class Trainer:
                     group_size = min(ga, n_batches - group_start)
                     micro += 1
                     accumulate = (micro - group_start) < group_size
+                    if tuner is not None and steps_this_run == 1 and not accumulate:
+                        # the second optimizer step of this run is an ordinary step with timing marks behind its
+                        # gradients (the first one re-plans the buckets from the observed gradient order)
+                        tuner.arm()
+                        tuner_armed = True
                     last_loss = self.train_step(batch, accumulate, group_size)
                     if accumulate:
                         continue
+                    if tuner_armed:
+                        self.bucket_decision = tuner.finish()  # every rank, same step; re-plans the buckets
+                        tuner, tuner_armed = None, False
+                        self._zero_grad()
                     batch_in_epoch = micro
                     self.global_step += 1
                     steps_this_run += 1
@@ -426,7 +466,7 @@ class Trainer:
                         if agreed & 1:
                             stopped = done = True
                     if cfg.save_every and cfg.checkpoint_path and self.global_step % cfg.save_every == 0:
-                        self.save(epoch, batch_in_epoch)
+                        self.save(epoch, batch_in_epoch, n_batches)
                     if cfg.steps and self.global_step >= cfg.steps:
                         done = True
                     if done:
@@ -436,6 +476,16 @@ class Trainer:
                     batch_in_epoch = 0
                 if done:
                     break
+            if env.distributed and check_every > 1:
+                # flags raised since the last agreement step (a NaN in the final steps, a stop request that arrived
+                # late) must not be lost when the loop ends: one more agreement, entered by every rank
+                if self.stopper.requested:
+                    pending |= 1
+                agreed = self._agree(pending)
+                if agreed & 2:
+                    raise FloatingPointError(f"non-finite loss at or before step {self.global_step} on some rank")
+                if agreed & 1:
+                    stopped = True
         finally:
             dog.stop()
             self.stopper.uninstall()
@@ -466,9 +516,11 @@ class Trainer:
                 rank_zero_print(f"Eval: loss {res.eval_loss:.4f}")
         if cfg.checkpoint_path:
             if done and batch_in_epoch:
-                self.save(epoch, batch_in_epoch)  # stopped inside an epoch: a resume continues behind this batch
+                # stopped inside an epoch: a resume continues behind this batch (or with the next epoch when it was
+                # the epoch's last one)
+                self.save(epoch, batch_in_epoch, len(loader))
             else:
-                self.save(epoch + 1, 0)
+                self.save(epoch + 1, 0, len(loader))
             rank_zero_print(f"Checkpoint written to {cfg.checkpoint_path}")
         if cfg.profile:
             if self.trace and env.is_main:
@@ -476,47 +528,62 @@ class Trainer:
             rank_zero_print(self.timer.format())
         return res
 
-    @torch.no_grad()
     def evaluate(self):
-        """Mean loss and top-1 accuracy over the (sharded) dataset, reduced across ranks."""
+        """Mean loss and top-1 accuracy over the dataset, reduced across ranks."""
+        loss_sum, correct, count = all_reduce_values(self.env, self.evaluate_totals(), "sum")
+        count = max(count, 1.0)
+        return loss_sum / count, (correct / count if self.kind == "image" else None)
+
+    @torch.no_grad()
+    def evaluate_totals(self):
+        """``[loss_sum, correct, count]`` over this rank's shard, every sample of the dataset counted by exactly one rank.
+
+        The sharded sampler pads the last positions of some shards by wrapping around so that all ranks see the same
+        number of samples; those repeats are cut off here (``valid_samples``), so the result does not depend on the
+        world size."""
         env = self.env
         was_training = self.model.training
         self.model.eval()
-        loader, _ = build_loader(self.dataset, self.cfg.batch_size, self.cfg.num_workers, env.rank, env.world_size,
-                                 shuffle=False, pin_memory=self.device.type == "cuda")
+        loader, sampler = build_loader(self.dataset, self.cfg.batch_size, self.cfg.num_workers, env.rank, env.world_size,
+                                       shuffle=False, pin_memory=self.device.type == "cuda")
+        valid = sampler.valid_samples
         if self.device.type == "cuda":  # uploads (and uint8 -> bf16 conversion) of batch k+1 overlap batch k
             loader = DevicePrefetcher(loader, self.device, convert=lambda u8: ops.image_batch_to_device_layout(u8, self.dtype))
         tot = torch.zeros(3, dtype=torch.float64, device=self.device)  # loss_sum, correct, count
+        seen = 0
         for batch in loader:
+            b = _batch_len(batch)
+            n = max(0, min(b, valid - seen))
+            seen += b
+            if n == 0:
+                continue
             if self.kind == "lm":
                 ids, targets = batch
-                loss = self.raw_model(ids.to(self.device), targets.to(self.device))
-                n = ids.shape[0]
+                loss = self.raw_model(ids[:n].to(self.device), targets[:n].to(self.device))
                 tot[0] += loss.double() * n
                 tot[2] += n
             else:
                 imgs, lbls = batch
-                lbls = lbls.to(self.device)
+                lbls = lbls.to(self.device)[:n]
                 if imgs.device != self.device or imgs.dtype != self.dtype:
                     imgs = prepare_image_batch(imgs, self.device, self.dtype)
-                preds = self.raw_model(imgs)
+                preds = self.raw_model(imgs[:n] if n < b else imgs)
                 loss = ops.softmax_cross_entropy(preds, lbls)
-                n = lbls.shape[0]
                 tot[0] += loss.double() * n
                 tot[1] += (preds.argmax(dim=1) == lbls).sum().double()
                 tot[2] += n
-        if env.distributed:
-            t = tot.to(torch.float32) if env.backend == "gloo" else tot
-            torch.distributed.all_reduce(t)
-            tot = t.to(torch.float64)
         self.model.train(was_training)
-        count = max(float(tot[2]), 1.0)
-        acc = float(tot[1]) / count if self.kind == "image" else None
-        return float(tot[0]) / count, acc
+        return tot.tolist()
 
-    def save(self, epoch: int, batch_in_epoch: int = 0) -> None:
+    def save(self, epoch: int, batch_in_epoch: int = 0, batches_per_epoch: int = 0) -> None:
+        """``(epoch, batch_in_epoch)`` is where a resumed run continues.  A position behind the last batch of an epoch
+        is the first batch of the next one: recorded that way, a resume neither replays the finished epoch nor
+        trains one epoch too many."""
+        if batches_per_epoch and batch_in_epoch >= batches_per_epoch:
+            epoch, batch_in_epoch = epoch + 1, 0
         ckpt.save_checkpoint(self.cfg.checkpoint_path, self.model, self.env, self.optimizer, epoch, self.global_step,
-                             extra={"batch_in_epoch": int(batch_in_epoch)})
+                             extra={"batch_in_epoch": int(batch_in_epoch), "batches_per_epoch": int(batches_per_epoch)},
+                             keep=self.cfg.keep_checkpoints)
 
     def close(self) -> None:
         if hasattr(self.model, "reducer"):

@@ -20,8 +20,9 @@ def init_rank(rank: int, world: int, port: int) -> None:
 
 
 def _gather_equal(t: torch.Tensor, world: int) -> bool:
+    t = t.detach().cpu().contiguous()  # the process group is the host control plane (gloo), also on GPU ranks
     parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t.contiguous())
+    dist.all_gather(parts, t)
     return all(torch.equal(parts[0], p) for p in parts)
 
 
@@ -130,7 +131,7 @@ def graphed_trainer_worker(rank: int, world: int, port: int, tmp: str) -> None:
 
     cfg = TrainConfig(distributed=True, model="resnet18", dataset="synthetic", dataset_length=16 * 8 * world,
                       batch_size=8, num_workers=0, learning_rate=0.05, optimizer="sgd", progress=False,
-                      device_data=True, hip_graph=True, graph_after=3, steps=10)
+                      device_data=True, hip_graph=True, graph_after=3, steps=10, bucket_mb=25.0)
     tr = Trainer(cfg)
     transport = tr.model.transport
     res = tr.fit()

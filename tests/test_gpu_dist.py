@@ -245,12 +245,47 @@ def test_bench_py_prints_one_json_line_with_sync_proofs():
 
 @pytest.mark.parametrize("main", ["null", "pool"])
 def test_data_parallel_step_with_a_prefetch_stream_and_host_run_ahead_makes_progress(main, free_port):
-    """Step stream + copy stream + communication stream + torch's communicator stream, host several steps ahead:
-    with a raised-priority communication stream this constellation stopped the device (the waiting priority queue
-    starved the queues that produce what it waits for); the communicator's stream has ordinary priority."""
+    """Step stream + copy stream + communication stream, host several steps ahead: with a raised-priority
+    communication stream and one more stream than hardware queues this constellation stopped the device (the waiting
+    priority queue starved the queues that produce what it waits for); the communicator's stream has ordinary priority
+    and the process has no other communicator."""
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_stream_worker.py")
     env = dict(os.environ, PORT=str(free_port), PROBE_MODEL="resnet50", PROBE_BATCH="256", PROBE_SIZE="224",
                PROBE_STEPS="20", PROBE_LIMIT="60", PROBE_MAIN=main)
     env.pop("PDT_COMM_PRIORITY", None)
     r = subprocess.run([sys.executable, "-u", worker], env=env, capture_output=True, text=True, timeout=120)
     assert "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_trainer_constellation_stays_within_the_hardware_queue_budget(free_port, tmp_path):
+    """The full trainer: host-fed input pipeline (copy stream), data parallelism (communication stream), the step
+    recorded into a hipGraph (capture stream) - the process must own at most as many streams as it is served hardware
+    queues (4), torch.distributed must not have brought up a communicator of its own, and the run must finish."""
+    code = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["PDT_ROOT"])
+import torch, torch.distributed as dist
+from pytorch_distributed_training_amd.train import TrainConfig, Trainer
+from pytorch_distributed_training_amd.utils.streams import stream_census
+cfg = TrainConfig(distributed=True, model="resnet18", dataset="synthetic", dataset_length=512, batch_size=32, num_workers=2,
+                  learning_rate=0.01, optimizer="sgd", progress=False, hip_graph=True, graph_after=3, steps=12, evaluate=True)
+tr = Trainer(cfg)
+res = tr.fit()
+c = stream_census()
+print("CENSUS " + json.dumps(dict(c, backend=dist.get_backend(), control=tr.env.control_backend, steps=res.steps,
+                                  replays=tr._graph.replays if tr._graph else 0, comm=tr.env.comm is not None)), flush=True)
+tr.close()
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PDT_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    r = subprocess.run([sys.executable, "-u", "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CENSUS ")][-1]
+    c = json.loads(line[len("CENSUS "):])
+    assert c["backend"] == "gloo" and c["control"] == "gloo" and c["comm"] is True and c["torch_nccl"] == 0
+    assert c["native"] == 1, c  # one communicator, one communication stream
+    assert c["steps"] == 12 and c["replays"] > 0
+    assert c["total"] <= 4 and c["budget"] == 4, c

@@ -95,17 +95,92 @@ def test_resume_continues_behind_the_batches_already_seen(tmp_path):
         assert torch.allclose(a, b, atol=1e-6), n
 
 
-def test_torn_checkpoint_pair_is_refused(tmp_path):
+def test_torn_checkpoint_pair_is_refused_when_no_generation_is_kept(tmp_path):
     import pytest
 
     from pytorch_distributed_training_amd.train.checkpoint import TornCheckpointError
 
     path = str(tmp_path / "m.pt")
     base = dict(use_cpu=True, dataset="synthetic", dataset_length=16, batch_size=4, num_workers=0, learning_rate=0.01,
-                progress=False)
+                progress=False, keep_checkpoints=0)
     Trainer(TrainConfig(**base, steps=2, checkpoint_path=path)).fit()
     side = open(path + ".resume", "rb").read()
     Trainer(TrainConfig(**base, steps=3, checkpoint_path=path)).fit()  # newer weights ...
     open(path + ".resume", "wb").write(side)  # ... next to the older sidecar: a crash between the two writes
     with pytest.raises(TornCheckpointError):
         Trainer(TrainConfig(**base, resume=path))
+    assert Trainer(TrainConfig(**base, resume="auto", checkpoint_path=path)).global_step == 0  # nothing whole: fresh start
+
+
+def test_torn_newest_checkpoint_falls_back_to_the_generation_before(tmp_path, capsys):
+    import os
+
+    from pytorch_distributed_training_amd.train import checkpoint as ckpt
+
+    path = str(tmp_path / "m.pt")
+    base = dict(use_cpu=True, dataset="synthetic", dataset_length=32, batch_size=4, num_workers=0, learning_rate=0.01,
+                progress=False)
+    Trainer(TrainConfig(**base, steps=2, checkpoint_path=path)).fit()
+    Trainer(TrainConfig(**base, steps=3, checkpoint_path=path, resume="auto")).fit()
+    Trainer(TrainConfig(**base, steps=5, checkpoint_path=path, resume="auto")).fit()
+    gens = ckpt.list_generations(path)
+    assert [g[0] for g in gens] == [5, 3]  # --keep-checkpoints 2: generation 2 was pruned
+    assert ckpt.pair_state(path) == "intact" and ckpt.find_resumable(path) == path
+    # the job dies after the newest generation's model file and before its sidecar, having already ... nothing else
+    os.remove(ckpt.resume_path(gens[0][1]))
+    # ... and, in another scenario, between re-pointing the main model file and the main sidecar
+    os.replace(gens[1][1] + ".resume", path + ".resume")
+    ckpt._link_over(path + ".resume", gens[1][1] + ".resume")
+    assert ckpt.pair_state(path) == "torn" and ckpt.pair_state(gens[0][1]) == "weights_only"
+    assert ckpt.find_resumable(path) == gens[1][1]
+    capsys.readouterr()
+    tr = Trainer(TrainConfig(**base, steps=6, checkpoint_path=path, resume="auto"))
+    out = capsys.readouterr().out
+    assert tr.global_step == 3 and "using the intact generation" in out and "step000000003" in out
+    tr.fit()
+    assert tr.global_step == 6 and ckpt.pair_state(path) == "intact"
+
+
+def test_checkpoint_on_the_last_batch_of_an_epoch_resumes_with_the_next_epoch(tmp_path):
+    """--steps equal to a whole number of epochs: the checkpoint is the start of the next epoch, so the resumed run
+    neither replays the finished epoch nor trains one too many, and ends where an uninterrupted run ends."""
+    path = str(tmp_path / "m.pt")
+    base = dict(use_cpu=True, dataset="synthetic", dataset_length=16, batch_size=4, num_workers=0, learning_rate=0.01,
+                optimizer="sgd", momentum=0.9, progress=False, seed=7, shuffle=True, epochs=3)
+    full = Trainer(TrainConfig(**base))
+    full.fit()
+    assert full.global_step == 12
+    first = Trainer(TrainConfig(**base, steps=8, checkpoint_path=path))  # stops on the last batch of epoch 1
+    first.fit()
+    second = Trainer(TrainConfig(**base, resume="auto", checkpoint_path=path))
+    assert (second.start_epoch, second.start_batch, second.global_step) == (2, 0, 8)
+    res = second.fit()
+    assert res.steps == 4 and res.epochs == 1 and second.global_step == 12
+    for (n, a), b in zip(full.raw_model.named_parameters(), second.raw_model.parameters()):
+        assert torch.allclose(a, b, atol=1e-6), n
+    # the same through --save-every landing on the boundary
+    path2 = str(tmp_path / "n.pt")
+    Trainer(TrainConfig(**base, steps=9, save_every=4, checkpoint_path=path2)).fit()
+    from pytorch_distributed_training_amd.train import checkpoint as ckpt
+
+    side = torch.load(ckpt.resume_path(ckpt.generation_path(path2, 8)), weights_only=True)
+    assert (side["epoch"], side["extra"]["batch_in_epoch"]) == (2, 0)
+
+
+def test_evaluation_counts_every_sample_once_for_any_world_size():
+    """10 samples on 3 ranks: the sampler pads the shards to 4 samples each by wrapping around; the totals must still be
+    those of the 10 samples."""
+    from pytorch_distributed_training_amd.parallel import DistEnv
+
+    base = dict(use_cpu=True, dataset="synthetic", dataset_length=10, batch_size=3, num_workers=0, progress=False, seed=2)
+    one = Trainer(TrainConfig(**base))
+    ref = one.evaluate_totals()
+    assert ref[2] == 10
+    parts = []
+    for r in range(3):
+        tr = Trainer(TrainConfig(**base), env=DistEnv(rank=r, world_size=3))
+        tr.raw_model.load_state_dict(one.raw_model.state_dict())
+        parts.append(tr.evaluate_totals())
+    assert [p[2] for p in parts] == [4, 3, 3]
+    tot = [sum(p[i] for p in parts) for i in range(3)]
+    assert tot[2] == 10 and tot[1] == ref[1] and abs(tot[0] - ref[0]) < 1e-4 * max(1.0, abs(ref[0]))

@@ -140,6 +140,49 @@ def test_batch_loader_delivers_vectorised_uint8_batches_in_order(tmp_path):
         assert seen == want
 
 
+def test_batch_loader_with_uneven_workers_never_starves_a_batch_and_awaits_upload_events():
+    """Workers that take turns being slow: whoever holds a batch number holds a buffer too, so the batch the consumer
+    waits for can always be filled.  A buffer with a registered upload event goes back to the ring only after the
+    event has been awaited."""
+    import random
+    import time
+
+    from pytorch_distributed_training_amd.data import BatchLoader
+    from pytorch_distributed_training_amd.data.sampler import ShardedSampler
+
+    class Slow:
+        def __len__(self):
+            return 64 * 4
+
+        def get_batch(self, idx, out=None):
+            time.sleep(random.Random(int(idx[0])).choice([0.0, 0.0, 0.02]))
+            imgs = idx.to(torch.uint8).view(-1, 1, 1, 1).expand(-1, 2, 2, 3)
+            if out is not None:
+                out.copy_(imgs)
+                imgs = out
+            return imgs, idx.clone()
+
+    class Event:
+        waited = 0
+
+        def synchronize(self):
+            Event.waited += 1
+
+    ds = Slow()
+    loader = BatchLoader(ds, 4, ShardedSampler(ds, shuffle=False), num_workers=4)
+    t0 = time.time()
+    got = []
+    for imgs, labels in loader:
+        loader.note_upload(imgs, Event())
+        got.append(int(labels[0]))
+        assert int(imgs[0, 0, 0, 0]) == int(labels[0]) % 256
+    assert got == list(range(0, 256, 4)) and time.time() - t0 < 30
+    assert Event.waited == 64  # every buffer's event was awaited before the buffer was reused or retired
+    it = iter(loader)  # a consumer that stops early leaves no worker behind
+    next(it)
+    it.close()
+
+
 def test_cifar10_python_batches_are_read_without_executing_pickle_code(tmp_path):
     import pickle
 
