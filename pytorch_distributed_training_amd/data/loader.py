@@ -167,6 +167,20 @@ class BatchLoader:
                 t.join(timeout=5)
 
 
+_copy_streams = {}
+
+
+def copy_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The process's one copy stream for ``device``.  Every prefetcher (training, evaluation, a second trainer in the
+    same process) uploads on it: a stream per prefetcher would push the process over the hardware queues it is
+    served (step + copy + communication + graph capture is the whole budget of four)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _copy_streams:
+        _copy_streams[key] = torch.cuda.Stream(device=device)
+    return _copy_streams[key]
+
+
 class DevicePrefetcher:
     """Wraps a host loader; overlaps the H2D copy of the next batch - and, for raw uint8 image batches, their
     conversion to the models' input form - with the current step.  ``convert(images_on_device) -> tensor`` runs on
@@ -176,7 +190,7 @@ class DevicePrefetcher:
         self.loader = loader
         self.device = torch.device(device)
         self.convert = convert
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.stream = copy_stream(self.device) if self.device.type == "cuda" else None
 
     def __len__(self) -> int:
         return len(self.loader)
