@@ -12,5 +12,10 @@ run "self all-reduce, no resident workgroups    " PDT_SELF_ALLREDUCE=1
 for gbps in 150 50; do for c in 16 32 64; do
 run "resident $c workgroups at $gbps GB/s          " PDT_SELF_ALLREDUCE=1 PDT_REHEARSE_CHANNELS=$c PDT_REHEARSE_GBPS=$gbps
 done; done
+# the footprint of a real collective's workgroup: 512 threads x 128 registers + 48 KB of LDS (cannot share a CU with a
+# 256-register ring workgroup)
+for gbps in 150 50; do for c in 16 32 64; do
+run "heavy resident $c workgroups at $gbps GB/s    " PDT_SELF_ALLREDUCE=1 PDT_REHEARSE_HEAVY=1 PDT_REHEARSE_CHANNELS=$c PDT_REHEARSE_GBPS=$gbps
+done; done
 run "resident 32 at 50 GB/s, 32 CUs reserved      " PDT_SELF_ALLREDUCE=1 PDT_REHEARSE_CHANNELS=32 PDT_REHEARSE_GBPS=50 PDT_RESERVE_CUS=32
 run "no collective, 32 CUs reserved               " PDT_RESERVE_CUS=32

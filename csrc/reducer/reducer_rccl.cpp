@@ -128,6 +128,20 @@ __global__ __launch_bounds__(256) void resident_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
+// The same with the footprint of a real collective's workgroup (PDT_REHEARSE_HEAVY=1): 512 threads that hold at
+// least 128 vector registers per lane and PDT_REHEARSE_LDS_KB (default 48) KB of LDS.  Two such waves per SIMD take half
+// of the register file, so a 256-register ring workgroup (two waves per SIMD, the whole file) cannot share the CU
+// with it - the situation the light variant (a handful of registers, no LDS) does not create.
+__global__ __launch_bounds__(512) void resident_heavy_kernel(long long ticks) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    asm volatile("" ::: "v127");  // the register allocation of the kernel reaches v127
+    lds[threadIdx.x * 16] = static_cast<char>(ticks);
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (lds[(threadIdx.x ^ 1) * 16] == 77 && ticks < 0) lds[0] = 1;  // keeps the LDS traffic above alive
+}
+
 // PDT_REHEARSE_CHANNELS=c (with a one-rank collective kept by PDT_SELF_ALLREDUCE=1): c resident workgroups per bucket;
 // PDT_REHEARSE_GBPS: the rate the bucket's duration is derived from (default 150, about one xGMI link).
 int rehearsal_channels() {
@@ -144,6 +158,25 @@ double rehearsal_gbps() {
         const char* e = std::getenv("PDT_REHEARSE_GBPS");
         v = e ? std::atof(e) : 150.0;
         if (v <= 0) v = 150.0;
+    }
+    return v;
+}
+
+bool rehearsal_heavy() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = std::getenv("PDT_REHEARSE_HEAVY");
+        v = (e && std::atoi(e) != 0) ? 1 : 0;
+    }
+    return v == 1;
+}
+int rehearsal_lds_bytes() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = std::getenv("PDT_REHEARSE_LDS_KB");
+        v = (e ? std::atoi(e) : 48) * 1024;
+        if (v < 8192) v = 8192;
+        if (v > 64 * 1024) v = 64 * 1024;
     }
     return v;
 }
@@ -216,7 +249,11 @@ static bool bucket_collective(PdtRcclBuckets* s, int b) {
         if (c->world == 1 && rehearsal_channels() > 0) {
             // ring all-reduce: every byte crosses a link twice; wall_clock64 ticks at 100 MHz
             const double seconds = 2.0 * static_cast<double>(n) * dtype_bytes(dt) / (rehearsal_gbps() * 1e9);
-            resident_kernel<<<rehearsal_channels(), 256, 0, c->stream>>>(static_cast<long long>(seconds * 1e8) + 1);
+            const long long ticks = static_cast<long long>(seconds * 1e8) + 1;
+            if (rehearsal_heavy())
+                resident_heavy_kernel<<<rehearsal_channels(), 512, rehearsal_lds_bytes(), c->stream>>>(ticks);
+            else
+                resident_kernel<<<rehearsal_channels(), 256, 0, c->stream>>>(ticks);
             if (!hip_ok(hipGetLastError(), "resident_kernel")) return false;
         }
     }
