@@ -111,13 +111,26 @@ EXTRA_FLAGS = {
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
+# Floating-point model per file.  -ffast-math tells the compiler that no NaN or infinity ever occurs
+# (finite-math-only), which is acceptable where a non-finite value can only pass through (the MFMA / attention
+# kernels: their arithmetic is MFMA instructions and explicit intrinsics) but not where the training loop relies on
+# seeing one: the loss and the optimizer keep IEEE semantics for NaN / Inf and only allow contraction into fused
+# multiply-adds.  (bn.hip stays on the fast model - its element-wise passes run at the memory roof and lose 2 % to the
+# NaN-aware forms of max() - and raises the non-finite flag --check-finite reads from an integer test of the exponent
+# bits, which no floating-point assumption can fold away.)
+PRECISE_MATH = {"loss.hip", "optim.hip"}
+
+
+def _math_flags(name: str) -> List[str]:
+    return ["-ffp-contract=fast", "-fno-math-errno"] if name in PRECISE_MATH else ["-ffast-math"]
+
 
 def _compile_kernel(src: Path, headers: List[Path], force: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
     if force or _newer(obj, [src] + headers + [Path(__file__)]):
         _run(
             [
-                _hipcc(), "-O3", "-std=c++17", "-fPIC", "-c", f"--offload-arch={ARCH}", "-ffast-math",
+                _hipcc(), "-O3", "-std=c++17", "-fPIC", "-c", f"--offload-arch={ARCH}", *_math_flags(src.name),
                 *EXTRA_FLAGS.get(src.name, []),
                 "-Wall", "-Wno-unused-function", f"-I{CSRC / 'kernels'}", "-o", str(obj), str(src),
             ]

@@ -18,22 +18,36 @@
 // ------------------------------------------------------------------------------------------------
 // bn_finalize: slots -> per-channel constants
 //   out consts layout: [4][C] = mean, rstd, scale, shift
+// The slots hold sums about a per-channel pivot P (sum(y - P), sum((y - P)^2)); P itself sits in the first row of
+// slot PDT_STAT_SLOTS (zero when the producer used none), so a copy of the slots stays self-contained:
+// mean = P + s1 / n and var = s2 / n - (s1 / n)^2, which loses nothing to cancellation while P is near the mean.  The
+// pivot buffer (optional) then receives this batch's mean for the next step's convolution to use.  A channel whose statistics
+// are not finite (an Inf or NaN reached the convolution) raises `nonfinite` (a device word the trainer's
+// --check-finite reads): BatchNorm followed by ReLU would otherwise swallow the NaN (max(NaN, 0) = 0).
 // ------------------------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const float* __restrict__ slots, int C, float count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    long long* num_batches, float momentum, float eps, int training,
-                                   float* __restrict__ consts) {
+                                   float* __restrict__ consts, float* pivot, int* nonfinite) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mean, var;
     if (training) {
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
         for (int s = 0; s < PDT_STAT_SLOTS; ++s) {
             s1 += slots[(s * 2 + 0) * C + c];
             s2 += slots[(s * 2 + 1) * C + c];
         }
-        mean = s1 / count;
-        var = fmaxf(s2 / count - mean * mean, 0.f);
+        const double d1 = s1 / count;
+        const float P = slots[PDT_STAT_SLOTS * 2 * C + c];
+        mean = static_cast<float>(static_cast<double>(P) + d1);
+        var = fmaxf(static_cast<float>(s2 / count - d1 * d1), 0.f);
+        // (integer tests of the exponent field: this file is compiled under finite-math assumptions, which would let
+        // the compiler fold a floating-point isfinite() to true)
+        const bool finite = (__float_as_uint(mean) & 0x7f800000u) != 0x7f800000u &&
+                            (__float_as_uint(static_cast<float>(s2)) & 0x7f800000u) != 0x7f800000u;
+        if (pivot != nullptr && finite) pivot[c] = mean;
+        if (nonfinite != nullptr && !finite) atomicOr(nonfinite, 1);
         if (running_mean != nullptr) {
             const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -54,10 +68,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ slots, int C, float
 
 PDT_API int pdt_bn_finalize(const float* slots, int C, float count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, long long* num_batches, float momentum, float eps,
-                            int training, float* consts, void* stream) {
+                            int training, float* consts, float* pivot, int* nonfinite, void* stream) {
     if (C <= 0 || (!training && (running_mean == nullptr || running_var == nullptr))) return -1;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(pdt_cdiv(C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), slots, C,
-                       count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, training, consts);
+                       count, gamma, beta, running_mean, running_var, num_batches, momentum, eps, training, consts, pivot,
+                       nonfinite);
     return pdt_launch_status();
 }
 

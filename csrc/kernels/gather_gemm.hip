@@ -34,7 +34,8 @@ struct GatherGemmArgs {
     const bf16* A;
     const bf16* B;
     bf16* Out;
-    float* stats;       // [PDT_STAT_SLOTS][2][N] zero-initialised (sum, sumsq) accumulators, or nullptr
+    float* stats;       // [PDT_STAT_SLOTS + 1][2][N] zero-initialised (sum, sumsq) accumulators, or nullptr; the last slot's
+                        // first row receives the pivot the sums were taken about (see `pivot`)
     const float* bias;  // [N] or nullptr
     const bf16* addend; // tensor with the layout of Out added to the result (residual gradient), or nullptr
     const uint8_t* addend_bits;  // optional ReLU mask for the addend: bit e of byte v gates element 8v + e
@@ -54,6 +55,10 @@ struct GatherGemmArgs {
     // BatchNorm + ReLU of the layer before this convolution applied to its raw output on the way in (xf = that
     // BatchNorm's [4][C] constants: mean, rstd, scale, shift).  The normalised activation tensor is never written.
     const float* xf;
+    // forward statistics are taken about a per-channel pivot: the slots receive sum(y - pivot) and sum((y - pivot)^2).
+    // With the pivot near the channel mean (the caller keeps the previous step's batch mean there) the variance is not
+    // formed as a difference of two large numbers.  nullptr: pivot 0.
+    const float* pivot;
     int act;
     int out_nt;  // ring variant: store the result rows non-temporally (outputs far larger than the caches; +2-3 % on
                  // the bandwidth-bound 1x1 layers of a 2048-image ResNet-50 step)
@@ -257,9 +262,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
     constexpr int NPASS = BM / RPP;
     const int ch = tid % CH, prow = tid / CH;
     const int ncol = n0 + ch * 8;
-    float s1[8], s2[8];
+    float s1[8], s2[8], pv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+        s1[e] = s2[e] = 0.f;
+        pv[e] = (p.pivot != nullptr && p.stats != nullptr && ncol < p.N) ? p.pivot[ncol + e] : 0.f;
+    }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int row = prow + ps * RPP;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = bf16_to_f32(v[e]);
+                const float f = bf16_to_f32(v[e]) - pv[e];
                 s1[e] += f;
                 s2[e] += f * f;
             }
@@ -314,8 +322,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
             const int which = idx / BN, col = idx - which * BN;
             float tot = 0.f;
             for (int r = 0; r < RPP; ++r) tot += sS[(r * 2 + which) * BN + col];
-            if (n0 + col < p.N)
+            if (n0 + col < p.N) {
                 __hip_atomic_fetch_add(slot + which * p.N + n0 + col, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the pivot travels with the sums (every workgroup of a column tile stores the same value)
+                if (which == 0 && p.pivot != nullptr)
+                    p.stats[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * p.N + n0 + col] = p.pivot[n0 + col];
+            }
         }
     }
 }
@@ -667,9 +679,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     float s1[8], s2[8], s3[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
+    // Forward statistics are accumulated about a pivot so that the variance is never a small difference of large sums.
+    // Inside the row groups the pivot is the first value the lane sees for each of its channels (f0v, exact in bf16; no
+    // load in the hot path); when the sums are flushed they are re-based to the launch's pivot p.pivot[c]:
+    // sum(y - P) = sum(y - f0) + n (f0 - P), sum((y - P)^2) = sum((y - f0)^2) + 2 (f0 - P) sum(y - f0) + n (f0 - P)^2.
+    bf16x8 f0v = {};
+    float fcnt = 0.f;
     int stats_n0 = -1;
     auto flush_stats = [&]() {
         if (NOSTATS || p.stats == nullptr || stats_n0 < 0) return;
+        if constexpr ((EPI & (12 | 48)) == 0) {
+            const int pc = stats_n0 + wn * TN + ech * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float P = (p.pivot != nullptr && pc < p.N) ? p.pivot[pc + e] : 0.f;
+                const float dl = bf16_to_f32(f0v[e]) - P;
+                s2[e] += dl * (2.f * s1[e] + fcnt * dl);
+                s1[e] += fcnt * dl;
+                // the pivot travels with the sums: last slot, first row (every flushing workgroup stores the same value)
+                if (p.pivot != nullptr && lane < CH && pc < p.N) p.stats[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * p.N + pc + e] = P;
+            }
+            fcnt = 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -1042,9 +1073,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                             if (EPI & 64) s3[e] += dz * bf16_to_f32(y2v[ps][e]);
                         }
                     } else if (!NOSTATS && p.stats != nullptr) {
+                        if (fcnt == 0.f) f0v = v;
+                        fcnt += 1.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float f = bf16_to_f32(v[e]);
+                            const float f = bf16_to_f32(v[e]) - bf16_to_f32(f0v[e]);
                             s1[e] += f;
                             s2[e] += f * f;
                         }
@@ -1178,7 +1211,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             int Wout, int ostr, int oph, int opw, const int* tap_dh, const int* tap_dw,
                             const int* tap_woff, int tile, int smallc, const void* zeros, const void* bn_y,
                             const float* bn_consts, const void* bn_bits, const void* bn_y2, const float* bn_consts2,
-                            int act, void* out2, const void* act_src, const float* xf, void* stream) {
+                            int act, void* out2, const void* act_src, const float* xf, const float* pivot, void* stream) {
     if (xf != nullptr && (smallc || tile != 16)) return -1;  // the operand transform lives in the 256x256 two-stage kernel
     if (act < 0 || act > 2 || (act == 1 && (out2 == nullptr || bias == nullptr)) || (act == 2 && act_src == nullptr)) return -1;
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
@@ -1204,6 +1237,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     if (bn_y2 != nullptr && bn_y == nullptr) return -1;
     a.stat_rows = bn_y != nullptr ? 3 : 2;
     a.xf = xf;
+    a.pivot = pivot;
     a.act = act;
     a.out_nt = g_out_nt_bytes < 0 ? (g_out_nt_bytes == -2 ? 3 : 2) : (static_cast<long long>(M) * N * 2 >= g_out_nt_bytes);
     a.out2 = static_cast<bf16*>(out2);

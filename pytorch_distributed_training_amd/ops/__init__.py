@@ -180,6 +180,14 @@ def add_bias_residual(x, bias, residual):
     return _ref.add_bias_residual(x, bias, residual)
 
 
+def nonfinite_seen(device, clear: bool = True) -> bool:
+    """Whether a GPU kernel met non-finite batch statistics since the last call (always False on the CPU path, where
+    PyTorch's own operators propagate NaN / Inf into the loss)."""
+    if torch.device(device).type == "cuda":
+        return _hip().nonfinite_seen(device, clear)
+    return False
+
+
 def prepare_module(module):
     """One-time per-model setup of the GPU path (no-op for CPU modules): lets weight-gradient kernels
     accumulate directly into ``.grad`` where that is safe."""

@@ -41,13 +41,13 @@ def _sig(name: str, argtypes):
     return fn
 
 
-_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp])
+_gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
 _wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp, _vp])
 _lib.pdt_wgrad_group_begin.argtypes = []
 _lib.pdt_wgrad_group_begin.restype = None
 _wgrad_group_end = _sig("pdt_wgrad_group_end", [_vp])
-_bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp])
+_bn_finalize = _sig("pdt_bn_finalize", [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp])
 _bn_apply_fwd = _sig("pdt_bn_apply_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp])
 _bn_bwd_reduce = _sig("pdt_bn_bwd_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp])
 _bn_bwd_finalize = _sig("pdt_bn_bwd_finalize", [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
@@ -502,13 +502,15 @@ def _pick_tile(m: int, n: int, ksteps: int = 1) -> int:
 
 
 def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Win, istr, OA, OB, Hout, Wout, ostr,
-                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None, gelu_out=None, gelu_of=None, xf=None) -> None:
+                        oph, opw, addend=None, smallc=0, addend_bits=None, bn_stat=None, gelu_out=None, gelu_of=None, xf=None,
+                        pivot=None) -> None:
     """``bn_stat = (y, consts, bits_or_None[, y2, consts2])``: also accumulate BatchNorm-backward sums of the result into ``stats``
     ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`).
     ``gelu_out``: tensor (layout of ``out``) that receives gelu(result) while ``out`` keeps the pre-activation.
     ``gelu_of``: pre-activation tensor (layout of ``out``); the result is multiplied by gelu'(gelu_of).
     ``xf``: [4, C] BatchNorm constants; the A operand is relu(a * scale + shift) per input channel, applied in the
-    kernel (single-tap launches on the 256x256 tile only, see :func:`_can_fuse_bn_into_conv`)."""
+    kernel (single-tap launches on the 256x256 tile only, see :func:`_can_fuse_bn_into_conv`).
+    ``pivot``: [N] fp32; the forward statistics in ``stats`` are taken about it (see :func:`_stat_pivot`)."""
     bn_y = bn_consts = bn_bits = bn_y2 = bn_consts2 = None
     if bn_stat is not None:
         bn_y, bn_consts, bn_bits = bn_stat[:3]
@@ -527,7 +529,7 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
                      tile, int(smallc),
                      _zero_page(a.device).data_ptr(), _ptr(bn_y), _ptr(bn_consts), _ptr(bn_bits), _ptr(bn_y2), _ptr(bn_consts2),
                      1 if gelu_out is not None else (2 if gelu_of is not None else 0), _ptr(gelu_out), _ptr(gelu_of), _ptr(xf),
-                     _stream()),
+                     _ptr(pivot) if stats is not None else None, _stream()),
         "gather_gemm",
     )
 
@@ -708,7 +710,8 @@ class _ConvStats(torch.autograd.Function):
             raise ValueError("output channels must be a multiple of 8")
         y = _empty_nhwc(nb, n, ho, wo, x.device)
         _check_size(y)
-        stats = ARENA.alloc((STAT_SLOTS, 2, n), x.device) if want_stats else None
+        stats = ARENA.alloc((STAT_SLOTS + 1, 2, n), x.device) if want_stats else None  # (+ the slot that carries the pivot)
+        pivot = _stat_pivot(weight) if want_stats else None
         ctx.geom = (nb, c, h, w_, n, r, s, ho, wo, stride, padding)
         ctx.col = None
         ctx.link = None
@@ -722,7 +725,8 @@ class _ConvStats(torch.autograd.Function):
         if c % 64 == 0:
             wb = SHADOWS.fwd(weight)
             taps = [(i - padding, j - padding, (i * s + j) * c) for i in range(r) for j in range(s)]
-            _launch_gather_gemm(x, wb, y, stats, None, M, n, r * s * c, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0)
+            _launch_gather_gemm(x, wb, y, stats, None, M, n, r * s * c, n, c, taps, h, w_, stride, ho, wo, ho, wo, 1, 0, 0,
+                                pivot=pivot)
             ctx.save_for_backward(x, weight)
         else:
             # few input channels (the stem), packed rows: the image is copied once into a zero-bordered buffer with
@@ -743,7 +747,7 @@ class _ConvStats(torch.autograd.Function):
             kpad = _round_up(r * tw, 64)
             wb = _packed_rows_weight(weight, cp, tw, kpad)
             _launch_gather_gemm(xp, wb, y, stats, None, M, n, kpad, n, cp, [(0, 0, 0)] * r, hp, wp, stride, ho, wo, ho, wo,
-                                1, 0, 0, smallc=tw)
+                                1, 0, 0, smallc=tw, pivot=pivot)
             ctx.save_for_backward(xp, weight)
             ctx.col = (kpad, cp, tw, hp, wp)
         if want_stats:
@@ -838,7 +842,54 @@ def conv2d_stats(x, weight, stride: int = 1, padding: int = 0, want_stats: bool 
     # of the block input) also reduces for the BatchNorm of the previous block's tail when that tail left a StatLink
     # on its output tensor
     stat_link = getattr(x, "_pdt_stat_link", None) if link is not None else None
-    return _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out, stat_link)
+    y, stats = _ConvStats.apply(x, weight, stride, padding, want_stats, link, link_out, stat_link)
+    if stats is not None:
+        stats._pdt_pivot = _stat_pivot(weight)  # BatchNorm's finalize leaves this batch's mean there for the next step
+    return y, stats
+
+
+STAT_PIVOT = int(_os.environ.get("PDT_STAT_PIVOT", "1"))  # 0: statistics about zero (sum y, sum y^2), for A/B runs
+
+
+def _stat_pivot(weight: torch.Tensor) -> Optional[torch.Tensor]:
+    """Per-output-channel pivot of a convolution's statistics (fp32, device memory, zero at first).
+
+    The convolution's epilogue accumulates sum(y - P) and sum((y - P)^2); with P = 0 the variance BatchNorm derives
+    from them is a difference of two large numbers for a channel whose mean is large against its spread.  The buffer
+    lives on the weight (one BatchNorm consumes one convolution's statistics), the kernel copies the value it used
+    into the statistics tensor, and ``bn_finalize`` writes the new batch mean back: from the second step on the pivot
+    tracks the mean.  Device-side state only: nothing is synchronised, a recorded step replays it."""
+    if not STAT_PIVOT:
+        return None
+    pv = getattr(weight, "_pdt_pivot", None)
+    if pv is None or pv.device != weight.device or pv.numel() != weight.shape[0]:
+        pv = torch.zeros(weight.shape[0], dtype=torch.float32, device=weight.device)
+        weight._pdt_pivot = pv
+    return pv
+
+
+_nonfinite_flags: Dict[torch.device, torch.Tensor] = {}
+
+
+def _nonfinite_flag(device) -> torch.Tensor:
+    """One int32 word per device that kernels raise when they meet statistics that are not finite."""
+    device = torch.device(device)
+    t = _nonfinite_flags.get(device)
+    if t is None:
+        t = _nonfinite_flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def nonfinite_seen(device, clear: bool = True) -> bool:
+    """Whether a kernel has seen non-finite batch statistics since the last call (BatchNorm followed by ReLU turns a
+    NaN into 0, so the loss alone does not show an Inf / NaN that entered further up).  Synchronises with the device."""
+    t = _nonfinite_flags.get(torch.device(device))
+    if t is None:
+        return False
+    seen = bool(int(t.item()))
+    if seen and clear:
+        t.zero_()
+    return seen
 
 
 def residual_link():
@@ -855,13 +906,19 @@ def _bn_consts(stats: Optional[torch.Tensor], bn: nn.BatchNorm2d, count: int, de
     training = bn.training or not bn.track_running_stats
     if training and stats is None:
         raise ValueError("training-mode BatchNorm needs the statistics produced by the convolution")
+    if training and tuple(stats.shape) != (STAT_SLOTS + 1, 2, c):
+        raise ValueError(f"statistics tensor of shape {tuple(stats.shape)}: expected {(STAT_SLOTS + 1, 2, c)} "
+                         "(accumulator slots + the slot that carries the pivot)")
+    pivot = getattr(stats, "_pdt_pivot", None) if training else None
+    if pivot is not None and (pivot.numel() != c or pivot.device != torch.device(device)):
+        pivot = None
     momentum = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats and bn.running_mean is not None
     _check(
         _bn_finalize(_ptr(stats), c, float(count), _ptr(bn.weight), _ptr(bn.bias),
                      _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
                      _ptr(bn.num_batches_tracked) if (track and training) else None, momentum, bn.eps,
-                     1 if training else 0, consts.data_ptr(), _stream()),
+                     1 if training else 0, consts.data_ptr(), _ptr(pivot), _nonfinite_flag(device).data_ptr(), _stream()),
         "bn_finalize",
     )
     return consts
@@ -1086,10 +1143,10 @@ class _BnReluConv1x1(torch.autograd.Function):
         consts = _bn_consts(stats_prev, bn, count, y_prev.device)
         y = _empty_nhwc(nb, n, h, w_, y_prev.device)
         _check_size(y)
-        stats = ARENA.alloc((STAT_SLOTS, 2, n), y_prev.device)
+        stats = ARENA.alloc((STAT_SLOTS + 1, 2, n), y_prev.device)
         one = [(0, 0, 0)]
         _launch_gather_gemm(y_prev, SHADOWS.fwd(weight), y, stats, None, M, n, c, n, c, one, h, w_, 1, h, w_, h, w_, 1, 0, 0,
-                            xf=consts)
+                            xf=consts, pivot=_stat_pivot(weight))
         ctx.save_for_backward(y_prev, consts, weight, gamma, beta)
         ctx.geom = (nb, c, h, w_, n)
         ctx.set_materialize_grads(False)
@@ -1127,10 +1184,14 @@ class _BnReluConv1x1(torch.autograd.Function):
 
 def bn_relu_conv2d(y_prev, stats_prev, bn, weight, stride: int = 1, padding: int = 0):
     if _can_fuse_bn_into_conv(y_prev, bn, weight, stride, padding):
-        return _BnReluConv1x1.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, weight)
-    sl = StatLink()  # the convolution's data-gradient kernel also reduces for BatchNorm's backward
-    a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True, sl)
-    return _ConvStats.apply(a, weight, stride, padding, bn.training, None, None, sl)
+        y, stats = _BnReluConv1x1.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, weight)
+    else:
+        sl = StatLink()  # the convolution's data-gradient kernel also reduces for BatchNorm's backward
+        a = _BnAct.apply(y_prev, stats_prev, bn.weight, bn.bias, bn, True, sl)
+        y, stats = _ConvStats.apply(a, weight, stride, padding, bn.training, None, None, sl)
+    if stats is not None:
+        stats._pdt_pivot = _stat_pivot(weight)
+    return y, stats
 
 
 def bn_add_relu(y, stats, bn, identity, id_stats=None, id_bn=None, link=None):

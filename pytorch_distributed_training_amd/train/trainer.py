@@ -451,7 +451,9 @@ class Trainer:
                         lv = float(last_loss) * group_size
                         loss_meter.update(lv)
                         res.losses.append(lv)
-                        if cfg.check_finite and not math.isfinite(lv):
+                        # (the kernels' flag catches an Inf / NaN that BatchNorm + ReLU would otherwise turn into zeros
+                        # before it reaches the loss)
+                        if cfg.check_finite and (not math.isfinite(lv) or ops.nonfinite_seen(self.device)):
                             pending |= 2
                         if env.is_main:
                             bar.set_postfix(loss=f"{lv:.4f}", refresh=False)

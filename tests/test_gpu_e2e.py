@@ -218,3 +218,26 @@ def test_gpt2_real_width_reduced_depth_matches_fp32_reference():
         lg.backward()
         opt_gpu.step()
         assert abs(float(lg) - float(lr_)) < 2e-2 * max(float(lr_), 1.0), (step, float(lg), float(lr_))
+
+
+def test_check_finite_sees_an_inf_that_batchnorm_and_relu_would_swallow():
+    """--check-finite on the GPU path: a weight poisoned with Inf produces NaN statistics in the first BatchNorm; ReLU
+    maps the NaN activations to zero and the loss stays finite, so only the kernels' non-finite flag can stop the run."""
+    import pytest as _pytest
+
+    from pytorch_distributed_training_amd.train import TrainConfig, Trainer
+
+    cfg = TrainConfig(model="resnet18", dataset="synthetic", dataset_length=64, batch_size=16, num_workers=0,
+                      learning_rate=0.01, optimizer="sgd", progress=False, log_every=1, check_finite=True, hip_graph=False,
+                      device_data=True, steps=3)
+    tr = Trainer(cfg)
+    with torch.no_grad():
+        tr.raw_model.layer1[0].conv1.weight[0, 0, 0, 0] = float("inf")
+    with _pytest.raises(FloatingPointError):
+        tr.fit()
+    tr.close()
+    ok = Trainer(TrainConfig(model="resnet18", dataset="synthetic", dataset_length=64, batch_size=16, num_workers=0,
+                             learning_rate=0.01, optimizer="sgd", progress=False, log_every=1, check_finite=True,
+                             hip_graph=False, device_data=True, steps=3))
+    assert ok.fit().steps == 3  # and a healthy run is not stopped
+    ok.close()

@@ -59,7 +59,7 @@ def test_conv_forward_backward(hip, nb, cin, cout, k, stride, pad, hw):
     yr = F.conv2d(xr, wr, None, stride, pad)
     assert y.shape == yr.shape and y.dtype == torch.bfloat16
     assert _rel_err(y, yr) < 6e-3
-    s = stats.sum(dim=0)
+    s = stats[:-1].sum(dim=0)  # (the last slot carries the pivot of the sums: zero here)
     yf = y.float()
     assert torch.allclose(s[0], yf.sum(dim=(0, 2, 3)), rtol=2e-3, atol=2e-2 * math.sqrt(yf[:, 0].numel()))
     assert torch.allclose(s[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=2e-3, atol=1e-2)
@@ -234,6 +234,69 @@ def test_bn_family_forward_backward(hip, nb, c, hw, variant):
     if variant == "proj":
         assert _rel_err(ident.grad, ir.grad) < 2e-2
         assert _rel_err(bn2.weight.grad, rbn2.weight.grad) < 2e-2
+
+
+@pytest.mark.parametrize("cout,hw", [(64, 28), (256, 14)])  # one-tile-per-workgroup kernel / persistent ring kernel
+def test_batch_statistics_of_a_channel_with_mean_far_above_its_spread(hip, cout, hw):
+    """mean / std = 10^3: E[y^2] - E[y]^2 in fp32 would cancel to noise (or to a negative number clamped to 0, i.e.
+    rstd = 1 / sqrt(eps)).  The sums are taken about a pivot that follows the batch mean, so from the second step on
+    the variance is accurate; the first step (pivot 0) must at least not be wildly off for moderate ratios."""
+    torch.manual_seed(3)
+    dev = _dev()
+    nb, cin = 16, 64
+    x = torch.randn(nb, cin, hw, hw, device=dev) * 0.5
+    x[:, 0] = 1.0  # a constant input channel: its weight sets the mean of an output channel
+    w = torch.randn(cout, cin, 1, 1, device=dev) * 0.25
+    w[:, 0] = 0.0
+    w[1, 0] = 1000.0  # channel 1: mean 1000, spread about 1
+    w[2, 0] = 100.0   # channel 2: mean 100
+    w = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+    xb = hip.to_device_layout(x)
+    bn = nn.BatchNorm2d(cout).to(dev)
+    count = nb * hw * hw
+    errs = []
+    for step in range(3):
+        y, st = hip.conv2d_stats(xb, w, 1, 0)
+        consts = hip._bn_consts(st, bn, count, y.device)
+        yd = y.detach().double()
+        mean = yd.mean(dim=(0, 2, 3))
+        var = yd.var(dim=(0, 2, 3), unbiased=False)
+        assert float(mean[1]) > 900 and float(var[1].sqrt()) < 5  # the case under test exists
+        assert torch.allclose(consts[0].double(), mean, rtol=1e-5, atol=1e-4), step
+        got_var = 1.0 / consts[1].double() ** 2 - bn.eps
+        errs.append(((got_var - var).abs() / var).cpu())
+    # pivot = the previous step's mean: every channel accurate, the extreme ones included
+    assert float(errs[1].max()) < 2e-3 and float(errs[2].max()) < 2e-3, (errs[1].max(), errs[2].max())
+    # first step (pivot 0): ordinary channels and the mean / std = 100 channel are fine already
+    ordinary = torch.ones(cout, dtype=torch.bool)
+    ordinary[1] = False
+    assert float(errs[0][ordinary].max()) < 2e-2, errs[0][ordinary].max()
+    # the pivot travels with the sums: a copy of the statistics tensor (which drops the Python-side link to the
+    # pivot buffer) still finalizes to the same constants
+    y, st = hip.conv2d_stats(xb, w, 1, 0)
+    a = hip._bn_consts(st.clone(), nn.BatchNorm2d(cout).to(dev), count, y.device)
+    b = hip._bn_consts(st, nn.BatchNorm2d(cout).to(dev), count, y.device)
+    assert torch.equal(a, b)
+
+
+def test_non_finite_statistics_raise_the_flag_that_check_finite_reads(hip):
+    """BatchNorm + ReLU turns a NaN into 0 (max(NaN, 0) = 0), so an Inf that enters a convolution never reaches the
+    loss; the statistics' finalize raises a device-side flag instead."""
+    dev = _dev()
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 8, 8, device=dev)
+    w = nn.Parameter((torch.randn(64, 64, 1, 1, device=dev) * 0.1).contiguous(memory_format=torch.channels_last))
+    bn = nn.BatchNorm2d(64).to(dev)
+    hip.nonfinite_seen(dev)  # clear
+    y, st = hip.conv2d_stats(hip.to_device_layout(x), w, 1, 0)
+    out = hip.bn_act(y, st, bn, True)
+    assert torch.isfinite(out.float()).all() and not hip.nonfinite_seen(dev)
+    x[1, 3, 2, 2] = float("inf")
+    y, st = hip.conv2d_stats(hip.to_device_layout(x), w, 1, 0)
+    out = hip.bn_act(y, st, bn, True)
+    torch.cuda.synchronize()
+    assert hip.nonfinite_seen(dev), "the Inf went unnoticed"
+    assert not hip.nonfinite_seen(dev)  # reading clears
 
 
 def test_bn_eval_uses_running_stats(hip):
@@ -423,6 +486,14 @@ def test_residual_link_fuses_shortcut_gradient_without_changing_it(hip, monkeypa
         return l
 
     monkeypatch.setattr(ops, "residual_link", spy)
+    # the statistics pivots settle on the batch means in the first forward pass: after it, two passes over the same
+    # batch are bit-identical in forward, and the comparison below sees the fused shortcut gradient alone
+    with torch.no_grad():
+        blk(x0)
+    links.clear()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.reset_running_stats()
     xa = x0.clone().requires_grad_(True)
     blk(xa).backward(g)
     assert len(links) == 1 and links[0].armed and links[0].consumed and links[0].grad is None  # produced and consumed
@@ -768,7 +839,7 @@ def test_bn_relu_fused_into_the_1x1_convolution_kernels(hip, monkeypatch, case):
         assert any(launched) == (fused and fusable), "the operand transform was (not) used"
         out.backward(g)
         torch.cuda.synchronize()
-        res[fused] = (out.float().clone(), stats.sum(0).clone(), yy.grad.float().clone(), bn.weight.grad.clone(),
+        res[fused] = (out.float().clone(), stats[:-1].sum(0).clone(), yy.grad.float().clone(), bn.weight.grad.clone(),
                       bn.bias.grad.clone(), w.grad.clone(), bn.running_mean.clone())
     for name, a, b in zip(("out", "stats", "dy", "dgamma", "dbeta", "dw", "running_mean"), res[True], res[False]):
         assert _rel_err(a, b) < 4e-3, name
