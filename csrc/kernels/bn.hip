@@ -34,18 +34,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ slots, int C, float
     float mean, var;
     if (training) {
         double s1 = 0.0, s2 = 0.0;
+        unsigned exp_all_ones = 0;  // any accumulator that holds an Inf or a NaN (tested on the loaded bits)
         for (int s = 0; s < PDT_STAT_SLOTS; ++s) {
-            s1 += slots[(s * 2 + 0) * C + c];
-            s2 += slots[(s * 2 + 1) * C + c];
+            const float a = slots[(s * 2 + 0) * C + c], b = slots[(s * 2 + 1) * C + c];
+            exp_all_ones |= static_cast<unsigned>((__float_as_uint(a) & 0x7f800000u) == 0x7f800000u) |
+                            static_cast<unsigned>((__float_as_uint(b) & 0x7f800000u) == 0x7f800000u);
+            s1 += a;
+            s2 += b;
         }
         const double d1 = s1 / count;
         const float P = slots[PDT_STAT_SLOTS * 2 * C + c];
         mean = static_cast<float>(static_cast<double>(P) + d1);
         var = fmaxf(static_cast<float>(s2 / count - d1 * d1), 0.f);
-        // (integer tests of the exponent field: this file is compiled under finite-math assumptions, which would let
-        // the compiler fold a floating-point isfinite() to true)
-        const bool finite = (__float_as_uint(mean) & 0x7f800000u) != 0x7f800000u &&
-                            (__float_as_uint(static_cast<float>(s2)) & 0x7f800000u) != 0x7f800000u;
+        // (integer tests of the exponent field of values as they were loaded: this file is compiled under finite-math
+        // assumptions, which would let the compiler fold a floating-point isfinite() to true)
+        const bool finite = exp_all_ones == 0;
         if (pivot != nullptr && finite) pivot[c] = mean;
         if (nonfinite != nullptr && !finite) atomicOr(nonfinite, 1);
         if (running_mean != nullptr) {

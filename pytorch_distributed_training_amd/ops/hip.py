@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os as _os
+import threading as _threading
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -146,8 +147,24 @@ class ZeroArena:
         self.buf: Optional[torch.Tensor] = None
         self.offset = 0
         self.enabled = True
+        self._threads: set = set()
+
+    def _check_thread(self) -> None:
+        """The arena (like the shadow-weight cache and the padded-gradient cache of this module) is process-wide state
+        that assumes ONE training loop: regions are handed out by the thread that runs forward and by autograd's
+        device thread that runs backward, strictly one after the other.  A third thread means two loops share the
+        process (two models trained concurrently): their steps would clear each other's accumulators."""
+        t = _threading.get_ident()
+        if t not in self._threads:
+            if len(self._threads) >= 2 and not _os.environ.get("PDT_ALLOW_THREADS"):
+                raise RuntimeError(
+                    "the GPU kernels' step arena is used from a third thread: this package assumes one training loop per "
+                    "process (forward on one thread, backward on autograd's device thread); run concurrent models in "
+                    "separate processes (PDT_ALLOW_THREADS=1 disables this check)")
+            self._threads.add(t)
 
     def alloc(self, shape, device) -> torch.Tensor:
+        self._check_thread()
         n = 1
         for s_ in shape:
             n *= int(s_)

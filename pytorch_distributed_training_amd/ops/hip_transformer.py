@@ -109,7 +109,19 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+LAYERNORM_MAX_WIDTH = 4096  # the kernels keep a row in the registers of one wave: 8 sixteen-byte vectors per lane
+
+
 def layer_norm(x, weight, bias, eps: float = 1e-5, link=None):
+    d = x.shape[-1]
+    if d > LAYERNORM_MAX_WIDTH or d % 8:
+        # wider (or oddly sized) rows than the register-resident kernels hold: PyTorch's operator, in fp32, with the
+        # skip connection's gradient (normally added inside the backward kernel) left to autograd
+        if link is not None:
+            raise ValueError(f"layer_norm over {d} features cannot take a fused skip-link: the HIP kernels handle rows of "
+                             f"up to {LAYERNORM_MAX_WIDTH} features (multiples of 8); call it without `link`")
+        return torch.nn.functional.layer_norm(x.float(), (d,), weight.float(), None if bias is None else bias.float(),
+                                              eps).to(x.dtype)
     return _LayerNorm.apply(x, weight, bias, eps, link)
 
 
