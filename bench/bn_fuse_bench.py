@@ -26,7 +26,7 @@ def main():
         w = nn.Parameter((torch.randn(cout, cin, 1, 1, device=dev) / math.sqrt(cin)).contiguous(memory_format=torch.channels_last))
         bn = nn.BatchNorm2d(cin).to(dev)
         yf = y.float()
-        st = torch.zeros(hip.STAT_SLOTS, 2, cin, device=dev)
+        st = torch.zeros(hip.STAT_SLOTS + 1, 2, cin, device=dev)  # (+ the slot that carries the pivot: zero)
         st[0, 0] = yf.sum(dim=(0, 2, 3))
         st[0, 1] = (yf * yf).sum(dim=(0, 2, 3))
         del yf

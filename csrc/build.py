@@ -115,10 +115,11 @@ EXTRA_FLAGS = {
 # (finite-math-only), which is acceptable where a non-finite value can only pass through (the MFMA / attention
 # kernels: their arithmetic is MFMA instructions and explicit intrinsics) but not where the training loop relies on
 # seeing one: the loss and the optimizer keep IEEE semantics for NaN / Inf and only allow contraction into fused
-# multiply-adds.  (bn.hip stays on the fast model - its element-wise passes run at the memory roof and lose 2 % to the
-# NaN-aware forms of max() - and raises the non-finite flag --check-finite reads from an integer test of the exponent
-# bits, which no floating-point assumption can fold away.)
-PRECISE_MATH = {"loss.hip", "optim.hip"}
+# multiply-adds, and so does the BatchNorm finalize kernel, which raises the non-finite flag --check-finite reads
+# (under finite-math-only even a bit test of the exponent field is folded away: the compiler may assume that no float
+# argument is an Inf or a NaN).  bn.hip's element-wise passes stay on the fast model - they run at the memory roof
+# and lose 2 % to the NaN-aware forms of max().
+PRECISE_MATH = {"loss.hip", "optim.hip", "bn_finalize.hip"}
 
 
 def _math_flags(name: str) -> List[str]:

@@ -251,8 +251,11 @@ def _empty_nhwc(n: int, c: int, h: int, w: int, device) -> torch.Tensor:
 
 
 def _check_size(t: torch.Tensor) -> None:
-    if t.numel() >= 2 ** 31:
-        raise ValueError("tensor too large for 32-bit element offsets")
+    """The gather loaders address activations with unsigned 32-bit element offsets (pixel index x channels; everything
+    behind them - output rows, BatchNorm / pooling passes, weight-gradient operands - uses 64-bit addresses), so one
+    activation tensor may hold up to 2^32 elements (8 GiB of bf16): ResNet-50 up to a batch of 5 300 per GPU."""
+    if t.numel() >= 2 ** 32:
+        raise ValueError(f"activation of {t.numel()} elements: the kernels address at most 2^32 elements per tensor")
 
 
 def to_device_layout(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:

@@ -299,6 +299,86 @@ def test_non_finite_statistics_raise_the_flag_that_check_finite_reads(hip):
     assert not hip.nonfinite_seen(dev)  # reading clears
 
 
+def test_activation_of_more_than_2_31_elements(hip):
+    """Convolution (forward, data gradient, weight gradient) and BatchNorm + ReLU (forward, backward) on an activation
+    whose element offsets do not fit a signed 32-bit integer: 11 000 images of 64 x 56 x 56 = 2.2e9 elements, the size
+    of a ResNet-50 stage-1 tensor at a batch of about 2 750 per channel-quarter.  Checked against fp32 matrix products
+    on the same bf16-rounded operands; the rows compared include the very last ones (highest offsets)."""
+    dev = _dev()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs about 70 GiB of free device memory")
+    torch.manual_seed(11)
+    nb, c, hw = 11000, 64, 56
+    M = nb * hw * hw
+    assert M * c > 2**31
+    x = torch.empty((nb, hw, hw, c), dtype=torch.bfloat16, device=dev)
+    for i in range(0, nb, 1000):  # filled in pieces: no fp32 copy of the whole tensor
+        x[i:i + 1000] = torch.randn((min(1000, nb - i), hw, hw, c), device=dev).to(torch.bfloat16)
+    xb = x.permute(0, 3, 1, 2).requires_grad_(True)  # logical NCHW, physically NHWC
+    w = nn.Parameter((torch.randn(c, c, 1, 1, device=dev) / 8).contiguous(memory_format=torch.channels_last))
+    bn = nn.BatchNorm2d(c).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    y, st = hip.conv2d_stats(xb, w, 1, 0)
+    out = hip.bn_act(y, st, bn, True)
+    g = torch.empty_like(out)
+    gp = g.permute(0, 2, 3, 1)
+    for i in range(0, nb, 1000):
+        gp[i:i + 1000] = torch.randn((min(1000, nb - i), hw, hw, c), device=dev).to(torch.bfloat16)
+    out.backward(g)
+    torch.cuda.synchronize()
+    # ---- fp32 reference, computed on slices (head, a middle piece straddling offset 2^31, tail) and globally for the
+    # reductions
+    wr = _bf16_round(w.detach()).view(c, c)
+    xf = x.view(M, c)
+    yk = y.permute(0, 2, 3, 1).reshape(M, c)
+    mean = torch.zeros(c, dtype=torch.float64, device=dev)
+    sq = torch.zeros(c, dtype=torch.float64, device=dev)
+    step = 4_000_000
+    for i in range(0, M, step):
+        yy = yk[i:i + step].double()
+        mean += yy.sum(0)
+        sq += (yy * yy).sum(0)
+    mean /= M
+    var = sq / M - mean * mean
+    rstd = 1.0 / torch.sqrt(var + bn.eps)
+    gamma, beta = bn.weight.detach().double(), bn.bias.detach().double()
+    gk = g.permute(0, 2, 3, 1).reshape(M, c)
+    ok = out.detach().permute(0, 2, 3, 1).reshape(M, c)
+    # global sums of BatchNorm's backward
+    sdz = torch.zeros(c, dtype=torch.float64, device=dev)
+    sdzx = torch.zeros(c, dtype=torch.float64, device=dev)
+    for i in range(0, M, step):
+        yy = yk[i:i + step].double()
+        xhat = (yy - mean) * rstd
+        dz = gk[i:i + step].double() * ((xhat * gamma + beta) > 0)
+        sdz += dz.sum(0)
+        sdzx += (dz * xhat).sum(0)
+    assert _rel_err(bn.bias.grad.double(), sdz) < 2e-2 and _rel_err(bn.weight.grad.double(), sdzx) < 2e-2
+    dw_ref = torch.zeros(c, c, dtype=torch.float64, device=dev)
+    half = 2**31 // c
+    for lo in (0, half - 3000, M - 6000):
+        sl = slice(lo, lo + 6000)
+        yr = xf[sl].float() @ wr.t()
+        assert _rel_err(yk[sl], yr) < 6e-3, lo
+        xhat = (yk[sl].double() - mean) * rstd
+        z = xhat * gamma + beta
+        assert _rel_err(ok[sl], torch.relu(z)) < 1e-2, lo
+        dz = gk[sl].double() * (z > 0)
+        dy = gamma * rstd * (dz - sdz / M - xhat * sdzx / M)
+        dx = dy.float() @ wr
+        assert _rel_err(xb.grad.permute(0, 2, 3, 1).reshape(M, c)[sl], dx) < 2e-2, lo
+    for i in range(0, M, step):
+        yy = yk[i:i + step].double()
+        xhat = (yy - mean) * rstd
+        dz = gk[i:i + step].double() * ((xhat * gamma + beta) > 0)
+        dy = (gamma * rstd * (dz - sdz / M - xhat * sdzx / M)).to(torch.bfloat16).double()
+        dw_ref += dy.t() @ xf[i:i + step].double()
+    assert _rel_err(w.grad.view(c, c).double(), dw_ref) < 2e-2
+
+
 def test_bn_eval_uses_running_stats(hip):
     dev = _dev()
     bn = nn.BatchNorm2d(64).to(dev).eval()
@@ -673,7 +753,7 @@ def test_bn_backward_sums_from_the_dgrad_epilogue_match_the_separate_reduction(h
         w = nn.Parameter((torch.randn(cout, cin, k, k, device=dev) / math.sqrt(cin * k * k)).contiguous(memory_format=torch.channels_last))
         gamma, beta = torch.empty(cin, device=dev).uniform_(0.5, 1.5), torch.empty(cin, device=dev).uniform_(-0.5, 0.5)
         yf = y.float()
-        st = torch.zeros(hip.STAT_SLOTS, 2, cin, device=dev)
+        st = torch.zeros(hip.STAT_SLOTS + 1, 2, cin, device=dev)  # (+ the slot that carries the pivot: zero)
         st[0, 0] = yf.sum(dim=(0, 2, 3))
         st[0, 1] = (yf * yf).sum(dim=(0, 2, 3))
         g = None
@@ -817,7 +897,7 @@ def test_bn_relu_fused_into_the_1x1_convolution_kernels(hip, monkeypatch, case):
     w = nn.Parameter((torch.randn(cout, cin, 1, 1, device=dev) / math.sqrt(cin)).contiguous(memory_format=torch.channels_last))
     gamma, beta = torch.empty(cin, device=dev).uniform_(0.5, 1.5), torch.empty(cin, device=dev).uniform_(-0.5, 0.5)
     yf = y.float()
-    st = torch.zeros(hip.STAT_SLOTS, 2, cin, device=dev)
+    st = torch.zeros(hip.STAT_SLOTS + 1, 2, cin, device=dev)  # (+ the slot that carries the pivot: zero)
     st[0, 0] = yf.sum(dim=(0, 2, 3))
     st[0, 1] = (yf * yf).sum(dim=(0, 2, 3))
     g = torch.randn(nb, cout, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
