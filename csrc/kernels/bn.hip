@@ -15,6 +15,10 @@
 // as exercised by /root/reference/src/main.py:49,74,78.
 #include "common.h"
 
+int pdt_deterministic_flag = 0;
+PDT_API void pdt_set_deterministic(int on) { pdt_deterministic_flag = on ? 1 : 0; }
+PDT_API int pdt_get_deterministic() { return pdt_deterministic_flag; }
+
 // (bn_finalize - slots -> per-channel constants - lives in bn_finalize.hip, which is compiled with IEEE NaN / Inf semantics)
 
 // ------------------------------------------------------------------------------------------------
@@ -275,6 +279,8 @@ static inline int reduce_rows_per_block(int M, int C) {
     const long long groups = (C + 63) / 64;
     long long blocks_x = 2048 / groups;
     if (blocks_x < 1) blocks_x = 1;
+    // deterministic mode: at most one row block per accumulator slot, so no slot has two adders
+    if (pdt_deterministic_flag && blocks_x > PDT_STAT_SLOTS) blocks_x = PDT_STAT_SLOTS;
     long long rpb = (M + blocks_x - 1) / blocks_x;
     rpb = (rpb + 31) / 32 * 32;
     return static_cast<int>(rpb < 32 ? 32 : rpb);
@@ -297,6 +303,62 @@ PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, 
     else if (mask_mode == 3) { if (second) PDT_RED(3, true); else PDT_RED(3, false); }
     else { if (second) PDT_RED(0, true); else PDT_RED(0, false); }
 #undef PDT_RED
+    return pdt_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward statistics by a pass of their own (deterministic mode, where the convolution epilogues do not accumulate
+// them with atomics): slot b of [PDT_STAT_SLOTS + 1][2][C] receives sum(y - P), sum((y - P)^2) over row block b, by
+// plain stores in a fixed order; the pivot P (or zero) goes to the first row of the last slot, as the epilogues do it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_rows_kernel(const bf16* __restrict__ y, const float* __restrict__ pivot,
+                                                           float* __restrict__ slots, int M, int C, int rows_per_block) {
+    __shared__ float red[32][2][64];
+    const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.y * 64 + chunk * 8;
+    const bool cok = c < C;
+    float pv[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        pv[e] = (cok && pivot != nullptr) ? pivot[c + e] : 0.f;
+        s1[e] = s2[e] = 0.f;
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    if (cok) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + static_cast<size_t>(r) * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = bf16_to_f32(v[e]) - pv[e];
+                s1[e] += d;
+                s2[e] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[rl][0][chunk * 8 + e] = s1[e];
+        red[rl][1][chunk * 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[r][which][col];
+        const int cc = blockIdx.y * 64 + col;
+        if (cc < C) {
+            slots[(static_cast<size_t>(blockIdx.x) * 2 + which) * C + cc] = t;
+            if (blockIdx.x == 0 && which == 0) slots[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * C + cc] = pivot != nullptr ? pivot[cc] : 0.f;
+        }
+    }
+}
+
+PDT_API int pdt_bn_stats_rows(const void* y, const float* pivot, float* slots, int M, int C, void* stream) {
+    if (M <= 0 || C <= 0 || (C % 8) != 0) return -1;
+    int rpb = pdt_cdiv(M, PDT_STAT_SLOTS);
+    rpb = pdt_cdiv(rpb, 32) * 32;
+    hipLaunchKernelGGL(bn_stats_rows_kernel, dim3(pdt_cdiv(M, rpb), pdt_cdiv(C, 64)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(y), pivot, slots, M, C, rpb);
     return pdt_launch_status();
 }
 

@@ -18,6 +18,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // Per-channel statistics are accumulated with atomics into this many independent slots.
 #define PDT_STAT_SLOTS 32
 
+// Deterministic mode (pdt_set_deterministic, defined in bn.hip): reductions whose result depends on the order of
+// floating-point atomic adds are launched so that every destination has exactly one adder, or not at all (the caller
+// takes a different path); results are then bit-identical from run to run, at a price in speed.
+extern int pdt_deterministic_flag;
+
 // Launch-status convention of every exported launcher: 0 = launched, otherwise a hipError_t value.
 static inline int pdt_launch_status() { return static_cast<int>(hipGetLastError()); }
 

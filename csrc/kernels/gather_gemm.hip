@@ -1310,6 +1310,9 @@ struct WgradArgs {
     int Hin, Win, istr, OA, OB;
     FastDiv div_ab, div_b, div_c;
     int m_per_split;
+    long long split_stride;  // elements between the destinations of consecutive pixel-range splits; 0: every split adds
+                             // into dW itself.  Non-zero (deterministic mode): split s adds into dW + s * split_stride, a
+                             // zeroed slab of its own, so every element has one adder and the caller sums the slabs in order
     int cp, tw;  // packed-row mode (few input channels): elements per pixel and per kernel row; C = T * tw columns
     int tap_dh[GG_MAX_TAPS];
     int tap_dw[GG_MAX_TAPS];
@@ -1473,8 +1476,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             for (int e = 0; e < 4; ++e) {
                 const int n = n0 + wr * TW + i * 16 + (lane >> 4) * 4 + e;
                 if (n < p.N && c < p.C)
-                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(n) * p.ldw + woff + c, acc[i][j][e],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(split) * p.split_stride + static_cast<size_t>(n) * p.ldw + woff + c,
+                                           acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 }
@@ -1942,8 +1945,8 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
             for (int e = 0; e < 4; ++e) {
                 const int n = n0 + wr * TN + i * 16 + (lane >> 4) * 4 + e;
                 if (n < p.N)
-                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(n) * p.ldw + wcol, acc[i][j][e], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(p.dW + static_cast<size_t>(split) * p.split_stride + static_cast<size_t>(n) * p.ldw + wcol,
+                                           acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     }
 }
@@ -2065,7 +2068,8 @@ PDT_API int pdt_wgrad_group_end(void* stream) {
 // dW must be zero (or hold a value to accumulate onto) before the call.
 PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, int ldy, int C, int T, int ldw, int Hin,
                       int Win, int istr, int OA, int OB, const int* tap_dh, const int* tap_dw, const int* tap_woff,
-                      int splits, int tile, int smallc, const void* zeros, float* dbias, const float* xf, void* stream) {
+                      int splits, int tile, int smallc, const void* zeros, float* dbias, const float* xf,
+                      long long split_stride, void* stream) {
     // rows of dY are read in 8-column chunks: ldy must cover N rounded up to 8 (columns >= N are ignored)
     if (M <= 0 || N <= 0 || C <= 0 || T <= 0 || T > GG_MAX_TAPS || (ldy % 8) != 0 || ldy < (N + 7) / 8 * 8) return -1;
     if (!smallc && (C % 8) != 0) return -1;
@@ -2077,6 +2081,8 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     a.zeros = static_cast<const bf16*>(zeros);
     a.dbias = dbias;
     a.xf = xf;
+    a.split_stride = split_stride;
+    if (split_stride != 0 && (wgrad_grouping || dbias != nullptr)) return -1;  // per-split slabs: single launches, no bias sums
     if (xf != nullptr && (tile < 10 || tile == 15 || smallc || wgrad_grouping)) return -1;  // ring kernels, single launches
     if (dbias != nullptr && (tile < 10 || tile == 15)) return -1;  // only the MODE 0 ring kernels sum the bias gradient
     a.M = M; a.N = N; a.ldy = ldy; a.C = C; a.T = T; a.ldw = ldw;

@@ -450,7 +450,7 @@ PDT_API int pdt_colsum(const void* x, float* out, int rows, int cols, int ld, vo
     if (rows <= 0 || cols <= 0 || (ld % 8) != 0 || ld < (cols + 7) / 8 * 8) return -1;
     const int groups = pdt_cdiv(cols, 64);
     int bx = 1024 / groups;
-    if (bx < 1) bx = 1;
+    if (bx < 1 || pdt_deterministic_flag) bx = 1;  // deterministic mode: one row block, so one adder per column
     int rpb = pdt_cdiv(rows, bx);
     rpb = pdt_cdiv(rpb, 32) * 32;
     hipLaunchKernelGGL(colsum_kernel, dim3(pdt_cdiv(rows, rpb), groups), dim3(256), 0, static_cast<hipStream_t>(stream),

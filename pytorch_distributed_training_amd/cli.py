@@ -80,6 +80,9 @@ from .train import TrainConfig, run_training
 @click.option("--check-finite", is_flag=True, default=False,
               help="stop with an error on a non-finite loss (checked on --log-every steps; distributed GPU jobs act on it "
                    "at the next agreement step, at most --stop-check-every steps later, and once more when the loop ends)")
+@click.option("--deterministic", is_flag=True, default=False,
+              help="bit-identical GPU results from run to run (weight gradients, BatchNorm sums and embedding gradients "
+                   "avoid order-dependent floating-point atomics); slower, for debugging divergence")
 @click.option("--hip-graph/--no-hip-graph", default=None,
               help="record the whole training step into a hipGraph after --graph-after eager steps (launch-bound configs); "
                    "default: automatic - on for single-GPU image runs of at most 64 x 224 x 224 input pixels per batch")

@@ -188,6 +188,13 @@ def nonfinite_seen(device, clear: bool = True) -> bool:
     return False
 
 
+def set_deterministic(on: bool) -> None:
+    """Run-to-run bit-identical GPU results (see ``ops.hip.set_deterministic``; ``PDT_DETERMINISTIC=1`` does the same at
+    import).  The CPU path is PyTorch's own operators and is not affected."""
+    if torch.cuda.is_available():
+        _hip().set_deterministic(on)
+
+
 def prepare_module(module):
     """One-time per-model setup of the GPU path (no-op for CPU modules): lets weight-gradient kernels
     accumulate directly into ``.grad`` where that is safe."""

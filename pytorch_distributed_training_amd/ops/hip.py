@@ -44,7 +44,10 @@ def _sig(name: str, argtypes):
 
 _gather_gemm = _sig("pdt_gather_gemm", [_vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 16 + [_ip, _ip, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp])
 _colsum = _sig("pdt_colsum", [_vp, _vp, _i, _i, _i, _vp])
-_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp, _vp])
+_wgrad = _sig("pdt_wgrad", [_vp, _vp, _vp] + [_i] * 11 + [_ip, _ip, _ip, _i, _i, _i, _vp, _vp, _vp, _ll, _vp])
+_bn_stats_rows = _sig("pdt_bn_stats_rows", [_vp, _vp, _vp, _i, _i, _vp])
+_lib.pdt_set_deterministic.argtypes = [_i]
+_lib.pdt_set_deterministic.restype = None
 _lib.pdt_wgrad_group_begin.argtypes = []
 _lib.pdt_wgrad_group_begin.restype = None
 _wgrad_group_end = _sig("pdt_wgrad_group_end", [_vp])
@@ -127,6 +130,34 @@ def _tap_arrays(taps):
         hit = _tap_array_cache[key] = (_int_array([t[0] for t in key]), _int_array([t[1] for t in key]),
                                        _int_array([t[2] for t in key]))
     return hit
+
+
+# ------------------------------------------------------------------------------------------------
+# deterministic mode
+# ------------------------------------------------------------------------------------------------
+DETERMINISTIC = False
+
+
+def set_deterministic(on: bool) -> None:
+    """Bit-identical results from run to run (``PDT_DETERMINISTIC=1`` switches it on at import), for telling a real
+    divergence between replicas or runs from floating-point noise.  Everything whose result depends on the order of
+    floating-point atomic adds takes another route:
+
+    * weight gradients: every pixel-range split of the reduction adds into a zeroed slab of its own and the slabs are
+      summed in a fixed order (instead of all splits adding into the gradient with atomics); bias gradients come from
+      a column-sum kernel with one adder per column;
+    * BatchNorm: forward statistics and backward sums are taken by reduction passes with one writer per accumulator slot
+      (instead of in the convolution / data-gradient epilogues with atomics);
+    * embedding gradients: tokens are sorted by id and summed per id in order.
+
+    Slower (extra passes over activations, small reduction grids); the arithmetic is otherwise the same."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    _lib.pdt_set_deterministic(int(DETERMINISTIC))
+
+
+if _os.environ.get("PDT_DETERMINISTIC", "0") not in ("", "0"):
+    set_deterministic(True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -537,6 +568,12 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
         if len(bn_stat) == 5:  # a second BatchNorm shares dz (projected shortcut): its sums go to the third row
             bn_y2, bn_consts2 = bn_stat[3:]
     dh, dw, wo = _tap_arrays(taps)
+    det_stats = None
+    if DETERMINISTIC and stats is not None and bn_stat is None:
+        # forward statistics: not in the epilogue (atomics), but by a pass of their own over the finished output
+        if ldo != N or ostr != 1 or oph or opw or OA != Hout or OB != Wout:
+            raise NotImplementedError("deterministic statistics need a densely stored output")
+        det_stats, stats = stats, None
     tile = _pick_tile(M, N, len(taps) * max(C // 64, 1))
     if _TILE_FUSED_TAIL >= 0 and bn_bits is not None and tile == 16:
         tile = _TILE_FUSED_TAIL
@@ -552,6 +589,8 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
                      _ptr(pivot) if stats is not None else None, _stream()),
         "gather_gemm",
     )
+    if det_stats is not None:
+        _check(_bn_stats_rows(out.data_ptr(), _ptr(pivot), det_stats.data_ptr(), M, N, _stream()), "bn_stats_rows")
 
 
 WGRAD_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_TARGET_BLOCKS", "640"))
@@ -641,13 +680,26 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         bt = 128 if tile == 0 else 64
         splits = _wgrad_splits(M, N, smallc * len(taps), 1, bt) if smallc else _wgrad_splits(M, N, C, len(taps), bt)
     dh, dwi, wo = _tap_arrays(taps)
-    fuse_bias = dbias is not None and tile >= 10 and tile != 15
+    fuse_bias = dbias is not None and tile >= 10 and tile != 15 and not DETERMINISTIC
+    target, stride, slabs = dw, 0, None
+    if DETERMINISTIC:
+        # one zeroed slab per split of the pixel range: every element of a slab has exactly one adder
+        if not dw.is_contiguous():
+            raise NotImplementedError("deterministic weight gradients need a densely stored destination")
+        stride = dw.numel()
+        slabs = torch.zeros((splits, stride), dtype=torch.float32, device=dw.device)
+        target = slabs
     _check(
-        _wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
+        _wgrad(dy.data_ptr(), x.data_ptr(), target.data_ptr(), M, N, ldy, C, len(taps), ldw, Hin, Win, istr, OA, OB, dh, dwi,
                wo, splits, tile, int(smallc), _zero_page(dy.device).data_ptr(), _ptr(dbias) if fuse_bias else None, _ptr(xf),
-               _stream()),
+               stride, _stream()),
         "wgrad",
     )
+    if slabs is not None:
+        total = slabs[0]
+        for k in range(1, splits):  # fixed order
+            total = total + slabs[k]
+        dw.view(-1).add_(total)
     return fuse_bias
 
 
@@ -672,8 +724,9 @@ class StatLink:
 
 
 def _dgrad_can_fuse_stats(launches) -> bool:
-    """True when every data-gradient launch (M, N) of a convolution runs on a ring kernel."""
-    return bool(launches) and all(_pick_tile(m, n) >= 13 for m, n in launches)
+    """True when every data-gradient launch (M, N) of a convolution runs on a ring kernel (never in deterministic
+    mode: the epilogue's sums are accumulated with atomics)."""
+    return not DETERMINISTIC and bool(launches) and all(_pick_tile(m, n) >= 13 for m, n in launches)
 
 
 class ResidualLink:
@@ -1426,13 +1479,14 @@ class _GeluMLP(torch.autograd.Function):
         dh = torch.empty_like(h)
         _launch_gather_gemm(gp, w2t, dh, None, None, M, hd, n, hd, n, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, gelu_of=h)
         # both weight gradients in one launch: the second problem's main loops cover the first one's atomic tail
-        if WGRAD_GROUP:
+        grouped = WGRAD_GROUP and not DETERMINISTIC  # (deterministic mode reads each launch's slabs right away)
+        if grouped:
             _lib.pdt_wgrad_group_begin()
         try:
             dw2, db2 = weight_and_bias_grads(gp, g, w2, b2, 3, 4, n, hd)
             dw1, db1 = weight_and_bias_grads(dh, x2, w1, b1, 1, 2, hd, k)
         finally:
-            if WGRAD_GROUP:
+            if grouped:
                 _check(_wgrad_group_end(_stream()), "wgrad (grouped)")
         # first layer's input gradient
         dx = None

@@ -200,7 +200,7 @@ class _Embedding(torch.autograd.Function):
         g2 = _bf16c(g).reshape(-1, d)
         sink = _grad_sink(ctx.weight, (vocab, d))  # no [vocab, d] temporary and no dense add when allowed
         dw = sink if sink is not None else torch.zeros((vocab, d), dtype=torch.float32, device=g.device)
-        _check(_emb_bwd(ids_c.data_ptr(), g2.data_ptr(), dw.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_bwd")
+        _embedding_grad(ids_c, g2, dw, d, vocab)
         return None, (None if sink is not None else dw)
 
 
@@ -244,13 +244,32 @@ class _TokenPositionEmbedding(torch.autograd.Function):
         dwte = dwpe = None
         if ctx.needs_input_grad[1]:
             buf, own = _param_grad_target(wte, (vocab, d), g.device)
-            _check(_emb_bwd(ids_c.data_ptr(), g2.data_ptr(), buf.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_bwd")
+            _embedding_grad(ids_c, g2.reshape(-1, d), buf, d, vocab)
             dwte = None if own else buf
         if ctx.needs_input_grad[2]:
             buf, own = _param_grad_target(wpe, tuple(wpe.shape), g.device)
             _check(_batch_rowsum(g2.data_ptr(), buf.data_ptr(), b, s, d, 0, s, _stream()), "batch_rowsum")
             dwpe = None if own else buf
         return None, dwte, dwpe
+
+
+def _embedding_grad(ids_c, g2, buf, d: int, vocab: int) -> None:
+    """``buf[ids[i]] += g2[i]``.  Normally a scatter-add with fp32 atomics; in deterministic mode the tokens are sorted
+    by id (stable) and each id's rows are summed in that order, so the result does not depend on arrival order."""
+    from . import hip as _h
+
+    if not _h.DETERMINISTIC:
+        _check(_emb_bwd(ids_c.data_ptr(), g2.data_ptr(), buf.data_ptr(), ids_c.numel(), d, vocab, _stream()), "embedding_bwd")
+        return
+    ok = (ids_c >= 0) & (ids_c < vocab)
+    ids_v, order = torch.sort(torch.where(ok, ids_c, torch.full_like(ids_c, vocab)), stable=True)
+    n_ok = int(ok.sum())
+    ids_v, order = ids_v[:n_ok], order[:n_ok]
+    if n_ok == 0:
+        return
+    uniq, counts = torch.unique_consecutive(ids_v, return_counts=True)
+    sums = torch.segment_reduce(g2.index_select(0, order).float(), "sum", lengths=counts, axis=0)
+    buf.index_add_(0, uniq, sums)  # distinct rows: one adder per element
 
 
 def token_position_embedding(ids, wte, wpe):

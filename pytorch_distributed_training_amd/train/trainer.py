@@ -93,6 +93,9 @@ class TrainConfig:
     dist_timeout_s: float = 600.0
     profile: str = ""  # path of a chrome trace with per-phase host spans
     check_finite: bool = False
+    # run-to-run bit-identical GPU arithmetic (no order-dependent floating-point atomics; slower): for telling a real
+    # divergence between runs or replicas from noise
+    deterministic: bool = False
     # record the whole step into a hipGraph after a few eager steps (GPU only).  None = automatic: on for single-GPU
     # image runs small enough to be bound by kernel launches (the reference's own configuration, ResNet-18 on 32x32
     # images with a batch of 32, runs 1.7x faster recorded), off otherwise
@@ -142,6 +145,8 @@ class Trainer:
             print(f"Process group initialized - WORLD_SIZE: {self.env.world_size}, RANK: {self.env.rank}", flush=True)
         torch.manual_seed(cfg.seed)
         self.device = self.env.device
+        if cfg.deterministic:
+            ops.set_deterministic(True)
         self.dtype = resolve_dtype(cfg, self.device)
         spec = MODELS[cfg.model]
         self.kind = spec.kind
