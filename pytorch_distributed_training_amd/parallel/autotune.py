@@ -22,6 +22,7 @@ The decision function is pure (``choose_capacities``) so it is unit-tested on sy
 
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -226,9 +227,14 @@ class BucketAutoTuner:
     the host control plane and re-plans every rank's buckets.  A single rank has nothing to tune: both calls do
     nothing and ``finish`` returns ``None``."""
 
-    def __init__(self, model, env, grad_dtype: str = "fp32"):
+    def __init__(self, model, env, grad_dtype: str = "fp32", force: Optional[bool] = None):
+        """``force`` (default: the ``PDT_FORCE_AUTOTUNE`` environment variable): run the whole procedure in a one-rank
+        group too - nothing can be gained there, but it executes every step of it (probe collectives on the RCCL
+        communicator, gradient timing marks, decision, re-planning under a live optimizer) on a single GPU."""
         self.model, self.env, self.grad_dtype = model, env, grad_dtype
-        self.active = bool(env.distributed and env.world_size > 1 and hasattr(model, "reducer"))
+        if force is None:
+            force = os.environ.get("PDT_FORCE_AUTOTUNE", "0") not in ("", "0")
+        self.active = bool(env.distributed and (env.world_size > 1 or force) and hasattr(model, "reducer"))
         self._profile: Optional[ReadyProfile] = None
         self.decision: Optional[Dict] = None
 

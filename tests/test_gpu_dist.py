@@ -289,3 +289,55 @@ tr.close()
     assert c["native"] == 1, c  # one communicator, one communication stream
     assert c["steps"] == 12 and c["replays"] > 0
     assert c["total"] <= 4 and c["budget"] == 4, c
+
+
+def test_bucket_autotune_runs_end_to_end_on_the_rccl_communicator(one_rank_group):
+    """The whole --bucket-mb auto procedure forced in a one-rank group: timing marks behind the gradients of an ordinary
+    step, probe collectives on the process's RCCL communicator, the decision, and the buckets re-planned under a live
+    fused optimizer (whose launch plan holds gradient addresses).  In deterministic mode the run must end bit-identical
+    to one that never re-planned: the tuner changes where gradients live, never what they are."""
+    from pytorch_distributed_training_amd import ops
+    from pytorch_distributed_training_amd.models import build_model
+    from pytorch_distributed_training_amd.optim import build_optimizer
+    from pytorch_distributed_training_amd.parallel import wrap_data_parallel
+    from pytorch_distributed_training_amd.parallel.autotune import BucketAutoTuner
+
+    env = one_rank_group
+    dev = env.device
+    x = ops.to_device_layout(torch.randn(16, 3, 64, 64, device=dev))
+    y = torch.randint(0, 10, (16,), device=dev)
+
+    def run(tune: bool):
+        torch.manual_seed(3)
+        m = build_model("resnet18", num_classes=10).to(dev).to(memory_format=torch.channels_last)
+        ops.prepare_module(m)
+        model = wrap_data_parallel(m, env, bucket_mb=25.0, first_bucket_mb=1.0)
+        opt = build_optimizer(list(m.parameters()), "sgd", 0.05, 1e-4, 0.9)
+        model.reducer.zero_grad()
+        decision = None
+        for i in range(5):
+            tuner = BucketAutoTuner(model, env, force=True) if (tune and i == 1) else None
+            if tuner is not None:
+                tuner.arm()
+            ops.softmax_cross_entropy(model(x), y).backward()
+            opt.step()
+            model.reducer.zero_grad()
+            if tuner is not None:
+                torch.cuda.synchronize()
+                decision = tuner.finish()
+                model.reducer.zero_grad()
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+        nb = len(model.reducer.buckets)
+        model.reducer.close()
+        return flat, decision, nb
+
+    ops.set_deterministic(True)
+    try:
+        a, _, nb_a = run(False)
+        b, d, nb_b = run(True)
+    finally:
+        ops.set_deterministic(False)
+    assert d is not None and d["bucket_mb"] > 0 and d["backward_ms"] > 0 and len(d["probe_us"]) == 5
+    assert nb_b == d["buckets"]
+    assert torch.equal(a, b)
