@@ -87,3 +87,38 @@ def test_stop_signal_to_one_rank_stops_all_ranks_at_the_same_step(tmp_path):
     assert out.count("Training complete") == 2
     side = torch.load(path + ".resume", weights_only=True)
     assert 0 < side["step"] < 400 * 12  # stopped early, on a step every rank agreed on
+
+
+@pytest.mark.parametrize("stage,resumed_step", [("link_model", 4), ("model", 2)])
+def test_writer_killed_inside_a_save_leaves_a_pair_the_restarted_job_resumes_from(tmp_path, stage, resumed_step):
+    """Rank 0 dies inside its second save (step 4): after the main model file has been re-pointed but before its
+    sidecar (`link_model`: the main pair is torn, generation 4 is complete), or after the generation's model file and
+    before its sidecar (`model`: generation 4 is unusable, the main pair still is generation 2).  The launcher starts
+    fresh workers, `--resume auto` finds the newest intact pair, and the job ends with the parameters of a run that was
+    never interrupted."""
+    ref = str(tmp_path / "ref.pt")
+    p = _launch(_port(), {}, ["--steps", "6", "--checkpoint-path", ref])
+    out, err = p.communicate(timeout=300)
+    assert p.returncode == 0, err[-3000:]
+
+    path = str(tmp_path / "job.pt")
+    marker = str(tmp_path / "fault_fired")
+    p = _launch(_port(), {"PDT_FAULT_INJECT_SAVE": f"2:{stage}", "PDT_FAULT_INJECT_ONCE_FILE": marker},
+                ["--steps", "6", "--save-every", "2", "--checkpoint-path", path, "--resume", "auto"], max_restarts=1)
+    out, err = p.communicate(timeout=420)
+    assert p.returncode == 0, err[-3000:]
+    assert os.path.exists(marker), "the fault was never injected"
+    assert f"dying in save #2 after stage '{stage}'" in err
+    assert "Resumed from" in out and f"step {resumed_step}" in out, out[-2000:]
+    if stage == "link_model":
+        assert "is torn or missing; using the intact generation" in out, out[-2000:]
+    side = torch.load(path + ".resume", weights_only=True)
+    assert side["step"] == 6
+    a = torch.load(ref, weights_only=True)
+    b = torch.load(path, weights_only=True)
+    assert a.keys() == b.keys()
+    for k in a:
+        if a[k].is_floating_point():
+            assert torch.allclose(a[k], b[k], atol=1e-6), k
+        else:
+            assert torch.equal(a[k], b[k]), k
