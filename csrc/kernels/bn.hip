@@ -19,6 +19,56 @@ int pdt_deterministic_flag = 0;
 PDT_API void pdt_set_deterministic(int on) { pdt_deterministic_flag = on ? 1 : 0; }
 PDT_API int pdt_get_deterministic() { return pdt_deterministic_flag; }
 
+// Deterministic mode, reductions over rows: every row block stores its partial sums to a scratch array (one writer per
+// element) and a second kernel folds them into the accumulator slots in block order - as many row blocks as the fast
+// path uses, so the pass still runs at memory speed.  The scratch array belongs to the stream the kernels run on (the
+// two launches are adjacent in it); it is allocated at the first use, which therefore must not lie inside a capture.
+static float* g_det_partials = nullptr;
+static size_t g_det_partials_floats = 0;
+static float* det_partials(size_t floats) {
+    if (floats > g_det_partials_floats) {
+        if (g_det_partials != nullptr) (void)hipFree(g_det_partials);
+        g_det_partials = nullptr;
+        g_det_partials_floats = 0;
+        const size_t want = floats < (size_t(1) << 20) ? (size_t(1) << 20) : floats;
+        if (hipMalloc(&g_det_partials, want * sizeof(float)) != hipSuccess) return nullptr;
+        g_det_partials_floats = want;
+    }
+    return g_det_partials;
+}
+
+// slots[s][w][c] = sum over blocks b = s, s + SLOTS, s + 2 SLOTS, ... (in that order) of partials[b][w][c]
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials, int nblk, int rows, int used_rows,
+                                                           int C, float* __restrict__ slots) {
+    const int c = blockIdx.x * 256 + threadIdx.x, w = blockIdx.y, sl = blockIdx.z;
+    if (c >= C || w >= used_rows) return;
+    float t = 0.f;
+    for (int b = sl; b < nblk; b += PDT_STAT_SLOTS) t += partials[(static_cast<size_t>(b) * rows + w) * C + c];
+    slots[(static_cast<size_t>(sl) * rows + w) * C + c] = t;
+}
+
+// dst[i] += slabs[0][i] + slabs[1][i] + ... (in that order): the per-split weight-gradient slabs of deterministic mode
+__global__ __launch_bounds__(256) void sum_slabs_kernel(float* __restrict__ dst, const float* __restrict__ slabs, int nsplit,
+                                                       long long n, long long stride) {
+    const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = slabs[i];
+    for (int k = 1; k < nsplit; ++k) t += slabs[k * stride + i];
+    dst[i] += t;
+}
+
+PDT_API int pdt_sum_slabs(float* dst, const float* slabs, int nsplit, long long n, long long stride, void* stream) {
+    if (nsplit <= 0 || n <= 0 || stride < n) return -1;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dst, slabs, nsplit, n, stride);
+    return pdt_launch_status();
+}
+
+static void launch_fold(const float* partials, int nblk, int rows, int used_rows, int C, float* slots, hipStream_t s) {
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(pdt_cdiv(C, 256), used_rows, PDT_STAT_SLOTS), dim3(256), 0, s, partials, nblk,
+                       rows, used_rows, C, slots);
+}
+
 // (bn_finalize - slots -> per-channel constants - lives in bn_finalize.hip, which is compiled with IEEE NaN / Inf semantics)
 
 // ------------------------------------------------------------------------------------------------
@@ -207,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
                                                            const bf16* __restrict__ y, const float* __restrict__ consts,
                                                            const bf16* __restrict__ y2,
                                                            const float* __restrict__ consts2, float* slots,
-                                                           int M, int C, int rows_per_block) {
+                                                           int M, int C, int rows_per_block, float* partials) {
     __shared__ float red[32][3][64];
     const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.y * 64 + chunk * 8;
@@ -269,8 +319,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
         for (int r = 0; r < 32; ++r) t += red[r][which][col];
         const int cc = blockIdx.y * 64 + col;
         if (cc < C) {
-            float* slot = slots + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 3 * C;
-            __hip_atomic_fetch_add(slot + which * C + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (partials != nullptr) {  // deterministic mode: one writer per element, folded by fold_partials_kernel
+                partials[(static_cast<size_t>(blockIdx.x) * 3 + which) * C + cc] = t;
+            } else {
+                float* slot = slots + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * 3 * C;
+                __hip_atomic_fetch_add(slot + which * C + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -279,8 +333,6 @@ static inline int reduce_rows_per_block(int M, int C) {
     const long long groups = (C + 63) / 64;
     long long blocks_x = 2048 / groups;
     if (blocks_x < 1) blocks_x = 1;
-    // deterministic mode: at most one row block per accumulator slot, so no slot has two adders
-    if (pdt_deterministic_flag && blocks_x > PDT_STAT_SLOTS) blocks_x = PDT_STAT_SLOTS;
     long long rpb = (M + blocks_x - 1) / blocks_x;
     rpb = (rpb + 31) / 32 * 32;
     return static_cast<int>(rpb < 32 ? 32 : rpb);
@@ -297,22 +349,30 @@ PDT_API int pdt_bn_bwd_reduce(const void* dout, const void* out, const void* y, 
     const bf16 *d = static_cast<const bf16*>(dout), *o = static_cast<const bf16*>(out), *yy = static_cast<const bf16*>(y),
                *yy2 = static_cast<const bf16*>(y2);
     const bool second = y2 != nullptr;
-#define PDT_RED(MK, SC) hipLaunchKernelGGL((bn_bwd_reduce_kernel<MK, SC>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb)
+    float* partials = nullptr;
+    if (pdt_deterministic_flag) {
+        partials = det_partials(static_cast<size_t>(g.x) * 3 * C);
+        if (partials == nullptr) return static_cast<int>(hipErrorOutOfMemory);
+    }
+#define PDT_RED(MK, SC) hipLaunchKernelGGL((bn_bwd_reduce_kernel<MK, SC>), g, b, 0, s, d, o, yy, consts, yy2, consts2, slots, M, C, rpb, partials)
     if (mask_mode == 1) { if (second) PDT_RED(1, true); else PDT_RED(1, false); }
     else if (mask_mode == 2) { if (second) PDT_RED(2, true); else PDT_RED(2, false); }
     else if (mask_mode == 3) { if (second) PDT_RED(3, true); else PDT_RED(3, false); }
     else { if (second) PDT_RED(0, true); else PDT_RED(0, false); }
 #undef PDT_RED
+    if (partials != nullptr) launch_fold(partials, static_cast<int>(g.x), 3, second ? 3 : 2, C, slots, s);
     return pdt_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // Forward statistics by a pass of their own (deterministic mode, where the convolution epilogues do not accumulate
-// them with atomics): slot b of [PDT_STAT_SLOTS + 1][2][C] receives sum(y - P), sum((y - P)^2) over row block b, by
-// plain stores in a fixed order; the pivot P (or zero) goes to the first row of the last slot, as the epilogues do it.
+// them with atomics): row block b stores sum(y - P), sum((y - P)^2) over its rows to partials[b][2][C], and
+// fold_partials_kernel adds them into the slots of [PDT_STAT_SLOTS + 1][2][C] in block order; the pivot P (or zero)
+// goes to the first row of the last slot, as the epilogues do it.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_stats_rows_kernel(const bf16* __restrict__ y, const float* __restrict__ pivot,
-                                                           float* __restrict__ slots, int M, int C, int rows_per_block) {
+                                                           float* __restrict__ slots, int M, int C, int rows_per_block,
+                                                           float* __restrict__ partials) {
     __shared__ float red[32][2][64];
     const int chunk = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.y * 64 + chunk * 8;
@@ -326,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_stats_rows_kernel(const bf16* __restri
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     if (cok) {
         for (int r = r0 + rl; r < r1; r += 32) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + static_cast<size_t>(r) * C + c);
+            const bf16x8 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(y + static_cast<size_t>(r) * C + c));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = bf16_to_f32(v[e]) - pv[e];
@@ -347,7 +407,7 @@ __global__ __launch_bounds__(256) void bn_stats_rows_kernel(const bf16* __restri
         for (int r = 0; r < 32; ++r) t += red[r][which][col];
         const int cc = blockIdx.y * 64 + col;
         if (cc < C) {
-            slots[(static_cast<size_t>(blockIdx.x) * 2 + which) * C + cc] = t;
+            partials[(static_cast<size_t>(blockIdx.x) * 2 + which) * C + cc] = t;
             if (blockIdx.x == 0 && which == 0) slots[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * C + cc] = pivot != nullptr ? pivot[cc] : 0.f;
         }
     }
@@ -355,10 +415,14 @@ __global__ __launch_bounds__(256) void bn_stats_rows_kernel(const bf16* __restri
 
 PDT_API int pdt_bn_stats_rows(const void* y, const float* pivot, float* slots, int M, int C, void* stream) {
     if (M <= 0 || C <= 0 || (C % 8) != 0) return -1;
-    int rpb = pdt_cdiv(M, PDT_STAT_SLOTS);
-    rpb = pdt_cdiv(rpb, 32) * 32;
-    hipLaunchKernelGGL(bn_stats_rows_kernel, dim3(pdt_cdiv(M, rpb), pdt_cdiv(C, 64)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(y), pivot, slots, M, C, rpb);
+    const int rpb = reduce_rows_per_block(M, C);
+    const int nblk = pdt_cdiv(M, rpb);
+    float* partials = det_partials(static_cast<size_t>(nblk) * 2 * C);
+    if (partials == nullptr) return static_cast<int>(hipErrorOutOfMemory);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_stats_rows_kernel, dim3(nblk, pdt_cdiv(C, 64)), dim3(256), 0, s, static_cast<const bf16*>(y), pivot,
+                       slots, M, C, rpb, partials);
+    launch_fold(partials, nblk, 2, 2, C, slots, s);
     return pdt_launch_status();
 }
 

@@ -695,11 +695,9 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
                stride, _stream()),
         "wgrad",
     )
-    if slabs is not None:
-        total = slabs[0]
-        for k in range(1, splits):  # fixed order
-            total = total + slabs[k]
-        dw.view(-1).add_(total)
+    if slabs is not None:  # added in split order by one kernel
+        _check(_lib.pdt_sum_slabs(ctypes.c_void_p(dw.data_ptr()), ctypes.c_void_p(slabs.data_ptr()), splits,
+                                  ctypes.c_longlong(stride), ctypes.c_longlong(stride), ctypes.c_void_p(_stream())), "sum_slabs")
     return fuse_bias
 
 
