@@ -38,8 +38,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=0,
-                    help="per-GPU batch; 0 = the model's default, sized for 288 GB of HBM (ResNet-50 2048: 77 GiB, "
-                         "ViT-B/16 1024: 60 GiB, GPT-2 medium 128: 107 GiB)")
+                    help="per-GPU batch; 0 = the model's default, sized for 288 GB of HBM (ResNet-50 4000: ~150 GiB, "
+                         "ViT-B/16 2216: ~130 GiB, GPT-2 medium 128: 107 GiB)")
     ap.add_argument("--model", type=str, default="resnet50")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--seq-len", type=int, default=1024)
@@ -90,7 +90,12 @@ def _claim_stdout():
     return real
 
 
-DEFAULT_BATCH = {"resnet50": 2048, "vit_b_16": 1024, "gpt2_medium": 128}
+# Per-GPU batch of each model.  Large, because the persistent kernels deal whole rounds of tiles to 256 CUs, and chosen so
+# that the layers with the fewest tiles fill their last round: ResNet-50's 7x7 and 14x14 stages have batch x 49 (x 196)
+# output rows, and 256x256 tiles of a 512- (256-) channel output make batch / 668.7 rounds - 4000 is just under six (2048
+# was 3.06: a fourth round for 6 % of a round's work); ViT-B/16's 768-wide layers make batch / 110.9 rounds (2216: just
+# under twenty).  Measured on one box: ResNet-50 2048 -> 4000 +2-3 %, ViT-B/16 1024 -> 2216 +3.7 % (bench/batch_sweep.sh).
+DEFAULT_BATCH = {"resnet50": 4000, "vit_b_16": 2216, "gpt2_medium": 128}
 
 # Context only, NOT measured in this run: stock PyTorch-ROCm 2.10 on one MI355X (bench/stock_baseline.py, MIOpen find
 # mode for ResNet-50), each at the largest batch measured for it.
