@@ -567,6 +567,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     const bf16* a_cur[AI];
     const bf16* b_cur[BI];
     int a_step[AI], b_step[BI];
+    // output row m reads input pixel m (linear layers, stride-1 1x1 convolutions): no index arithmetic in the loader
+    const bool a_identity = p.istr == 1 && p.OA == p.Hin && p.OB == p.Win;
     auto plain_tile = [&](int tile) {
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
         const bool live = tile < total_tiles;
@@ -574,12 +576,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         for (int i = 0; i < AI; ++i) {
             const int m = tile_m * BM + row_a(i) + lrow;
             if (live && m < p.M) {
-                const uint32_t img = fastdiv(m, p.div_ab);
-                const uint32_t rem = m - img * (p.OA * p.OB);
-                const uint32_t a = fastdiv(rem, p.div_b);
-                const uint32_t b = rem - a * p.OB;
-                const size_t pixel = static_cast<size_t>(img) * (p.Hin * p.Win) + (a * p.istr) * p.Win + b * p.istr;
-                a_cur[i] = p.A + pixel * p.C + kchunk;
+                size_t pixel = static_cast<uint32_t>(m);
+                if (!a_identity) {
+                    const uint32_t img = fastdiv(m, p.div_ab);
+                    const uint32_t rem = m - img * (p.OA * p.OB);
+                    const uint32_t a = fastdiv(rem, p.div_b);
+                    const uint32_t b = rem - a * p.OB;
+                    pixel = static_cast<size_t>(img) * (p.Hin * p.Win) + (a * p.istr) * p.Win + b * p.istr;
+                }
+                a_cur[i] = p.A + pixel * static_cast<uint32_t>(p.C) + kchunk;
                 a_step[i] = BK;
             } else {
                 a_cur[i] = p.zeros;
@@ -628,7 +633,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     };
 
     f32x4 acc[FM][FN];
-    auto compute = [&](int slot) {
+    // `first` (a std::bool_constant): the first K-step of a tile starts from zero - its first 32-deep slice feeds the
+    // MFMAs a constant-zero accumulator operand, so the 128 accumulator registers are never cleared with moves (a
+    // quarter of the vector instructions a tile with a single K-step issues outside its MFMAs).
+    // (Not on the plain schedule of the 256x256 tile: two copies of its K-step leave the register allocator ~150 bytes of
+    // scratch per lane; that kernel clears its accumulators with moves.)
+    constexpr bool PEEL = PP || !(BM == 256 && BN == 256);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int slot, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         const bf16* sA = ring + slot * STAGE;
         const bf16* sB = sA + BM * BK;
         // every 32-deep slice of the K-step has its own fragment registers, so the reads of the next slice (or
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], (FIRST && kk == 0) ? zero4 : acc[i][j], 0, 0, 0);
         // Pinned schedule.  Reads are issued in the order of the loops above (per 32-deep slice: B fragments, then
         // A fragments by row block), MFMAs row block by row block; a fragment is read a few MFMA groups before
         // its use and is dead right after it, which keeps the live fragment registers far below KK * (FM + FN).
@@ -777,17 +790,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         const int tile = first + ti * G;
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
+        if constexpr (!PEEL) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
         if constexpr (BIAS_LDS) {
             const float* src = p.bias + min(n0 + wn * TN + lane, p.N - 1);
             __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)bias_row, 4, 0, 0);
         }
         if constexpr (PP) {
-            for (int s = 0; s < nsteps; ++s, ++g) {
+            auto pp_step = [&](auto first) {
+                constexpr bool FIRST = decltype(first)::value;
                 const bf16* sA = ring + slot * STAGE;
                 const bf16* sB = sA + BM * BK;
                 bf16x8 fa[2][4], fbl[2][2], fbh[2][2];
@@ -821,8 +837,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
-                                acc[ih * 4 + i][jh * 2 + j] =
-                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+                                acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    fb[kk][j], fa[kk][i], (FIRST && kk == 0) ? zero4 : acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_barrier" ::: "memory");
@@ -845,9 +861,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 pp_unit(1);
                 mfma_quadrant(1, 0, fbl);
                 slot ^= 1;
-            }
-        } else
-        for (int s = 0; s < nsteps; ++s, ++g) {
+            };
+            pp_step(std::true_type{});
+            for (int s = 1; s < nsteps; ++s) pp_step(std::false_type{});
+            g += nsteps;
+        } else {
+        auto ring_step = [&](int s, auto first) {
             if constexpr (PLAIN) {
                 // NS - 1 stages are always in flight here (the loader never stops issuing)
                 wait_vm_and_barrier<(NS - 2) * LPW>();
@@ -877,17 +896,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
-                compute(slot);
+                compute(slot, first);
                 plain_advance();
             } else {
                 // stage g was issued NS - 1 steps ago; NS - 2 younger stages stay in flight
                 wait_vm_and_barrier<(NS - 2) * LPW>();
                 // every wave has finished reading the stage of step g - 1: refill it
                 issue_stage();
-                compute(slot);
+                compute(slot, first);
                 advance_cursor();
             }
             slot = slot + 1 == NS ? 0 : slot + 1;
+        };
+        if constexpr (PEEL) {
+            if (nsteps > 0) {
+                ring_step(0, std::true_type{});
+                for (int s = 1; s < nsteps; ++s) ring_step(s, std::false_type{});
+            } else {  // a launch without taps (the untouched phases of a strided data gradient) stores zeros (+ addend)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = zero4;
+            }
+        } else {
+            for (int s = 0; s < nsteps; ++s) ring_step(s, std::false_type{});
+        }
+        g += nsteps;
         }
 
         // ---- epilogue (wave-private): 16 rows at a time -> bf16 -> LDS -> 16-byte row segments
@@ -921,6 +955,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         bool rok_[3][NPS];
         bf16x8 yv_[3][NPS], av_[3][NPS], y2v_[3][NPS];
         unsigned amb_[3][NPS], bnb_[3][NPS];
+        // Densely stored outputs: row m of the tile is row m of Out, so a group's offsets are the tile's first offset plus
+        // a wave-uniform multiple of the row pitch (one 64-bit multiply per tile instead of one per pass).  Rows beyond M
+        // are not stored; where the epilogue also loads operands of the output's layout they read the last valid row.
+        constexpr bool EPI_LOADS = (EPI & (2 | 12 | 16 | 64)) != 0;
+        const size_t dense_base = static_cast<size_t>(static_cast<uint32_t>(m0 + wm * TM + erow)) * static_cast<uint32_t>(p.ldo) + min(ncol, p.N - 8);
+        const size_t dense_last = static_cast<size_t>(static_cast<uint32_t>(p.M - 1)) * static_cast<uint32_t>(p.ldo) + min(ncol, p.N - 8);
         auto fetch = [&](int i, int st) {
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
@@ -928,7 +968,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 rok_[st][ps] = m < p.M && ncol < p.N;
                 const int mc = min(m, p.M - 1);
                 if (dense_out) {  // output pixel m is row m of Out (linear layers, stride-1 convolutions): no index arithmetic
-                    pixo_[st][ps] = static_cast<size_t>(mc) * p.ldo + min(ncol, p.N - 8);
+                    const size_t o = dense_base + static_cast<size_t>(static_cast<uint32_t>((i * 16 + ps * RPP) * p.ldo));
+                    pixo_[st][ps] = (EPI_LOADS && m >= p.M) ? dense_last : o;
                 } else {
                     const uint32_t img = fastdiv(mc, p.div_ab);
                     const uint32_t rem = mc - img * (p.OA * p.OB);
