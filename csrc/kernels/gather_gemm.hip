@@ -563,44 +563,41 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         }
     };
 
-    // PLAIN loader state: running source pointer and per-stage advance (BK elements, or 0 on the zero page)
-    const bf16* a_cur[AI];
-    const bf16* b_cur[BI];
-    int a_step[AI], b_step[BI];
+    // PLAIN loader state: a wave-uniform address per operand (origin of the tile's rows + K position, held in scalar
+    // registers and advanced by scalar adds) and this lane's byte offsets from it, which change once per tile.  The DMA
+    // instructions take "scalar base + 32-bit vector offset", so a K-step costs no vector arithmetic and the loader holds
+    // 8 vector registers (running 64-bit pointers and per-piece strides held 24 and cost 16-24 instructions per K-step).
+    // Rows beyond M (columns beyond N) re-read the last valid row: what they produce is neither stored nor counted in
+    // the statistics, and past its last tile the loader re-reads tile 0, which nothing consumes.
+    const char* a_base = nullptr;
+    const char* b_base = nullptr;
+    uint32_t a_lane[AI], b_lane[BI];
     // output row m reads input pixel m (linear layers, stride-1 1x1 convolutions): no index arithmetic in the loader
     const bool a_identity = p.istr == 1 && p.OA == p.Hin && p.OB == p.Win;
+    auto pixel_of = [&](int m) -> size_t {
+        if (a_identity) return static_cast<uint32_t>(m);
+        const uint32_t img = fastdiv(m, p.div_ab);
+        const uint32_t rem = m - img * (p.OA * p.OB);
+        const uint32_t a = fastdiv(rem, p.div_b);
+        const uint32_t b = rem - a * p.OB;
+        return static_cast<size_t>(img) * (p.Hin * p.Win) + (a * p.istr) * p.Win + b * p.istr;
+    };
     auto plain_tile = [&](int tile) {
-        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-        const bool live = tile < total_tiles;
+        const int t = tile < total_tiles ? tile : 0;
+        const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+        const int mt = tile_m * BM, nt = tile_n * BN;
+        const size_t pix0 = pixel_of(mt);
+        a_base = reinterpret_cast<const char*>(p.A + pix0 * static_cast<uint32_t>(p.C));
+        b_base = reinterpret_cast<const char*>(p.B + static_cast<size_t>(nt) * p.ldb + p.tap_woff[0]);
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int m = tile_m * BM + row_a(i) + lrow;
-            if (live && m < p.M) {
-                size_t pixel = static_cast<uint32_t>(m);
-                if (!a_identity) {
-                    const uint32_t img = fastdiv(m, p.div_ab);
-                    const uint32_t rem = m - img * (p.OA * p.OB);
-                    const uint32_t a = fastdiv(rem, p.div_b);
-                    const uint32_t b = rem - a * p.OB;
-                    pixel = static_cast<size_t>(img) * (p.Hin * p.Win) + (a * p.istr) * p.Win + b * p.istr;
-                }
-                a_cur[i] = p.A + pixel * static_cast<uint32_t>(p.C) + kchunk;
-                a_step[i] = BK;
-            } else {
-                a_cur[i] = p.zeros;
-                a_step[i] = 0;
-            }
+            const int m = min(mt + row_a(i) + lrow, p.M - 1);
+            a_lane[i] = (static_cast<uint32_t>(pixel_of(m) - pix0) * static_cast<uint32_t>(p.C) + kchunk) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int n = tile_n * BN + row_b(i) + lrow;
-            if (live && n < p.N) {
-                b_cur[i] = p.B + static_cast<size_t>(n) * p.ldb + p.tap_woff[0] + kchunk;
-                b_step[i] = BK;
-            } else {
-                b_cur[i] = p.zeros;
-                b_step[i] = 0;
-            }
+            const int n = min(nt + row_b(i) + lrow, p.N - 1) - nt;
+            b_lane[i] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(p.ldb) + kchunk) * 2u;
         }
     };
     auto plain_pieces = [&](int a_lo, int a_hi, int b_lo, int b_hi) {
@@ -609,22 +606,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             if (i < a_lo || i >= a_hi) continue;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)a_cur[i], (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
-            a_cur[i] += a_step[i];
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(a_base + a_lane[i]), (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (i < b_lo || i >= b_hi) continue;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)b_cur[i], (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
-            b_cur[i] += b_step[i];
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(b_base + b_lane[i]), (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
         }
     };
     auto plain_issue = [&]() {
         plain_pieces(0, AI, 0, BI);
         ld_slot = ld_slot + 1 == NS ? 0 : ld_slot + 1;
     };
+    // (called after the last piece of a stage has been issued)
     auto plain_advance = [&]() {
         ld_c0 += BK;
+        a_base += BK * 2;
+        b_base += BK * 2;
         if (ld_c0 >= p.C) {
             ld_c0 = 0;
             ld_tile += G;
