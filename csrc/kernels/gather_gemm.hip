@@ -691,11 +691,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = s3[e] = 0.f;
     // Forward statistics are accumulated about a pivot so that the variance is never a small difference of large sums.
-    // Inside the row groups the pivot is the first value the lane sees for each of its channels (f0v, exact in bf16; no
+    // Inside the row groups the pivot is the first value the lane sees for each of its channels (f0f, exact in bf16; no
     // load in the hot path); when the sums are flushed they are re-based to the launch's pivot p.pivot[c]:
     // sum(y - P) = sum(y - f0) + n (f0 - P), sum((y - P)^2) = sum((y - f0)^2) + 2 (f0 - P) sum(y - f0) + n (f0 - P)^2.
-    bf16x8 f0v = {};
+    float f0f[8];  // (as floats: converting a packed pivot for every chunk cost as much as the sums themselves)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f0f[e] = 0.f;
     float fcnt = 0.f;
+    bool f0_fresh = true;  // the next chunk this lane stages becomes its pivot (set by every flush; wave-uniform)
     int stats_n0 = -1;
     auto flush_stats = [&]() {
         if (NOSTATS || p.stats == nullptr || stats_n0 < 0) return;
@@ -704,13 +707,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float P = (p.pivot != nullptr && pc < p.N) ? p.pivot[pc + e] : 0.f;
-                const float dl = bf16_to_f32(f0v[e]) - P;
+                const float dl = f0f[e] - P;
                 s2[e] += dl * (2.f * s1[e] + fcnt * dl);
                 s1[e] += fcnt * dl;
                 // the pivot travels with the sums: last slot, first row (every flushing workgroup stores the same value)
                 if (p.pivot != nullptr && lane < CH && pc < p.N) p.stats[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * p.N + pc + e] = P;
             }
             fcnt = 0.f;
+            f0_fresh = true;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1062,6 +1066,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(epi + row * EP + (((ech ^ row) & (CH - 1)) << 3));
                 // rows 8-15 were staged with the two 8-byte halves of every 16-byte slot exchanged (see the staging layout)
                 if (RPP <= 8 ? ((ps * RPP) & 8) != 0 : (row & 8) != 0) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+                if constexpr (!NOSTATS && (EPI & (12 | 48)) == 0) {
+                    // The local pivot: whatever this lane stages first after a flush, a row beyond M included (such a row
+                    // holds finite values nobody uses - any finite pivot is exact, a close one only keeps the sums small).
+                    // Only the first chunk of a tile can be that one: a scalar branch at one place in the unrolled code.
+                    if (i == 0 && ps == 0 && f0_fresh) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f0f[e] = bf16_to_f32(v[e]);
+                        f0_fresh = false;
+                    }
+                }
                 if (rok[ps]) {
                     const size_t o = pixo[ps];
                     if (EPI & 2) {
@@ -1112,11 +1126,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                             if (EPI & 64) s3[e] += dz * bf16_to_f32(y2v[ps][e]);
                         }
                     } else if (!NOSTATS && p.stats != nullptr) {
-                        if (fcnt == 0.f) f0v = v;
                         fcnt += 1.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float f = bf16_to_f32(v[e]) - bf16_to_f32(f0v[e]);
+                            const float f = bf16_to_f32(v[e]) - f0f[e];
                             s1[e] += f;
                             s2[e] += f * f;
                         }
