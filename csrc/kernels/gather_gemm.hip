@@ -634,9 +634,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     // `first` (a std::bool_constant): the first K-step of a tile starts from zero - its first 32-deep slice feeds the
     // MFMAs a constant-zero accumulator operand, so the 128 accumulator registers are never cleared with moves (a
     // quarter of the vector instructions a tile with a single K-step issues outside its MFMAs).
-    // (Not on the plain schedule of the 256x256 tile: two copies of its K-step leave the register allocator ~150 bytes of
-    // scratch per lane; that kernel clears its accumulators with moves.)
-    constexpr bool PEEL = PP || !(BM == 256 && BN == 256);
+    // On the plain schedule of the 256x256 tile a second copy of the pinned K-step costs ~150 bytes of scratch per lane,
+    // so the single-tap flavours there run their first K-step unpinned (the scheduler is left to place its reads), and
+    // the multi-tap, operand-transform and bias flavours - which spill inside the tile loop even so - clear their
+    // accumulators with moves as before.
+    constexpr bool PEEL = PP || !(BM == 256 && BN == 256) || (PLAIN && !XF && (EPI & 1) == 0);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int slot, auto first) {
         constexpr bool FIRST = decltype(first)::value;
@@ -673,6 +675,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
         constexpr int READS = KK * (FM + FN), GROUPS = KK * FM;
         constexpr int LEAD = FN + 2;                                   // reads issued before the first MFMA
         constexpr int PER = (READS - LEAD + GROUPS - 2) / (GROUPS - 1) > 1 ? 2 : 1;  // reads after each MFMA group
+        if constexpr (FIRST && BM == 256 && BN == 256) return;  // (unpinned: see PEEL)
         __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0);
 #pragma unroll
         for (int gi = 0; gi < GROUPS; ++gi) {
