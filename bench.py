@@ -207,10 +207,16 @@ def main():
         make = synthetic_image_batches(args.batch_size, args.image_size, 1000, "cpu", seed=env.rank)
         batches = []
         for i in range(2):
-            x, y = make(i)
-            x = x.to(dev)
-            x = ops.to_device_layout(x, torch.bfloat16) if on_gpu else x
-            batches.append((x, y.to(dev)))
+            if on_gpu:
+                # generated on the device (a 4000-image fp32 batch is 2.4 GB: eight ranks would draw 40 GB on the host)
+                g = torch.Generator(device=dev).manual_seed(2 * env.rank + i)
+                x = torch.rand((args.batch_size, 3, args.image_size, args.image_size), device=dev, generator=g)
+                y = torch.randint(0, 1000, (args.batch_size,), device=dev, generator=g)
+                batches.append((ops.to_device_layout(x, torch.bfloat16), y))
+                del x
+            else:
+                x, y = make(i)
+                batches.append((x.to(dev), y.to(dev)))
 
     def zero_grad():
         if env.distributed:
