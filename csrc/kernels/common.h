@@ -63,6 +63,15 @@ __device__ __forceinline__ float pdt_gelu_sigmoid(float x, float x2) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u2));
 }
 __device__ __forceinline__ float pdt_gelu(float x) { return x * pdt_gelu_sigmoid(x, x * x); }
+// gelu(x) and gelu'(x) from one evaluation of the logistic function (the fused feed-forward block stores both in
+// forward, so that its backward multiplies by a stored number instead of evaluating two transcendentals per element)
+__device__ __forceinline__ void pdt_gelu_both(float x, float& g, float& d) {
+    const float x2 = x * x;
+    const float s = pdt_gelu_sigmoid(x, x2);
+    const float du2 = 2.f * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+    g = x * s;
+    d = s + g * (1.f - s) * du2;
+}
 __device__ __forceinline__ float pdt_gelu_grad(float x) {
     const float x2 = x * x;
     const float s = pdt_gelu_sigmoid(x, x2);

@@ -49,8 +49,8 @@ struct GatherGemmArgs {
     const bf16* bn_y2;         // tails with a projected shortcut: the shortcut BatchNorm's input (layout of Out) ...
     const float* bn_consts2;   // ... and constants; the third row of a slot then receives sum dz * xhat2
     int stat_rows;             // rows per slot of `stats`: 2 (forward statistics) or 3 (backward sums)
-    // activation fused into the epilogue: 1 = also store gelu(result) to out2 (Out keeps the pre-activation for the
-    // backward pass); 2 = multiply the result by gelu'(act_src), act_src being that pre-activation (layout of Out)
+    // activation fused into the epilogue: 1 = store gelu(result) to out2 and gelu'(result) to Out (what the backward
+    // pass needs); 2 = multiply the result by act_src, the derivative stored by such a launch (layout of Out)
     // ring variant, single-tap launches: the A operand is relu(A * scale[k] + shift[k]) per input channel k, i.e. the
     // BatchNorm + ReLU of the layer before this convolution applied to its raw output on the way in (xf = that
     // BatchNorm's [4][C] constants: mean, rstd, scale, shift).  The normalised activation tensor is never written.
@@ -289,15 +289,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
             if (p.act == 2) {
                 const bf16x8 hv = *reinterpret_cast<const bf16x8*>(p.act_src + pix * p.ldo + ncol);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(hv[e])));
+                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * bf16_to_f32(hv[e]));
             }
-            *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
             if (p.act == 1) {
                 bf16x8 gv;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gv[e] = f32_to_bf16(pdt_gelu(bf16_to_f32(v[e])));
+                for (int e = 0; e < 8; ++e) {
+                    float g, d;
+                    pdt_gelu_both(bf16_to_f32(v[e]), g, d);
+                    gv[e] = f32_to_bf16(g);
+                    v[e] = f32_to_bf16(d);
+                }
                 *reinterpret_cast<bf16x8*>(p.out2 + pix * p.ldo + ncol) = gv;
             }
+            *reinterpret_cast<bf16x8*>(p.Out + pix * p.ldo + ncol) = v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = bf16_to_f32(v[e]) - pv[e];
@@ -379,7 +384,7 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 
 // EPI selects what the epilogue reads besides the accumulators (bit mask): 1 bias, 2 addend (+ mask bits),
 // 4 BatchNorm-backward sums with the ReLU mask recomputed from bn_y, 8 the same with the mask from bn_bits,
-// 16 result times gelu'(act_src), 32 gelu(result) stored to out2 as well, 64 (with 8) sums for a second BatchNorm
+// 16 result times act_src (a stored gelu'), 32 gelu(result) to out2 and gelu'(result) in place of the result, 64 (with 8) sums for a second BatchNorm
 // that shares dz (the shortcut BatchNorm of a projected block tail), 128 no channel statistics at all (a launch
 // without a statistics request: the partial sums carried across tiles would only cost registers - on the ping-pong
 // schedule, which runs at the 256-register limit, they made the compiler spill, and every reload of a spilled
@@ -1086,9 +1091,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                         for (int e = 0; e < 8; ++e)
                             v[e] = f32_to_bf16(bf16_to_f32(v[e]) + (((amb[ps] >> e) & 1u) ? bf16_to_f32(av[ps][e]) : 0.f));
                     }
-                    if (EPI & 16) {
+                    if (EPI & 16) {  // act_src holds gelu' of the pre-activation, stored by the forward launch (EPI & 32)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * pdt_gelu_grad(bf16_to_f32(yv[ps][e])));
+                        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(bf16_to_f32(v[e]) * bf16_to_f32(yv[ps][e]));
+                    }
+                    if (EPI & 32) {
+                        // gelu(result) goes to out2, gelu'(result) takes the result's place in Out: the backward pass
+                        // needs the derivative, never the pre-activation itself
+                        bf16x8 gv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float g, d;
+                            pdt_gelu_both(bf16_to_f32(v[e]), g, d);
+                            gv[e] = f32_to_bf16(g);
+                            v[e] = f32_to_bf16(d);
+                        }
+                        *reinterpret_cast<bf16x8*>(p.out2 + o) = gv;
                     }
                     if (!NOSTATS && p.out_nt == 2) {
                         // (measurement aid: no output store at all, see pdt_set_out_nt_bytes)
@@ -1100,12 +1118,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
                         asm volatile("" ::: "memory");
                     } else {
                         *reinterpret_cast<bf16x8*>(p.Out + o) = v;
-                    }
-                    if (EPI & 32) {
-                        bf16x8 gv;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) gv[e] = f32_to_bf16(pdt_gelu(bf16_to_f32(v[e])));
-                        *reinterpret_cast<bf16x8*>(p.out2 + o) = gv;
                     }
                     if (EPI & 48) {
                         // linear layers: no channel statistics

@@ -557,8 +557,9 @@ def _launch_gather_gemm(a, b, out, stats, bias, M, N, ldb, ldo, C, taps, Hin, Wi
                         pivot=None) -> None:
     """``bn_stat = (y, consts, bits_or_None[, y2, consts2])``: also accumulate BatchNorm-backward sums of the result into ``stats``
     ([slots][3][N]); only the ring kernels can do that (see :func:`_dgrad_can_fuse_stats`).
-    ``gelu_out``: tensor (layout of ``out``) that receives gelu(result) while ``out`` keeps the pre-activation.
-    ``gelu_of``: pre-activation tensor (layout of ``out``); the result is multiplied by gelu'(gelu_of).
+    ``gelu_out``: tensor (layout of ``out``) that receives gelu(result); ``out`` receives gelu'(result), the factor the
+    backward pass needs (the pre-activation itself is never stored).
+    ``gelu_of``: that derivative tensor (layout of ``out``); the result is multiplied by it.
     ``xf``: [4, C] BatchNorm constants; the A operand is relu(a * scale + shift) per input channel, applied in the
     kernel (single-tap launches on the 256x256 tile only, see :func:`_can_fuse_bn_into_conv`).
     ``pivot``: [N] fp32; the forward statistics in ``stats`` are taken about it (see :func:`_stat_pivot`)."""
@@ -1398,9 +1399,10 @@ class _Linear(torch.autograd.Function):
 
 class _GeluMLP(torch.autograd.Function):
     """out = gelu(x W1^T + b1) W2^T + b2 (+ residual) as four GEMM launches forward+backward-data and two
-    weight-gradient launches, with every element-wise step inside a GEMM epilogue: the first GEMM stores the
-    pre-activation and its GELU, the second adds bias and residual, the data-gradient GEMM of the second layer
-    multiplies by gelu' on the way out, and the weight-gradient kernels sum the bias gradients."""
+    weight-gradient launches, with every element-wise step inside a GEMM epilogue: the first GEMM stores the GELU of
+    its result and, in place of the result, the GELU's derivative (both from one evaluation of the logistic function),
+    the second adds bias and residual, the data-gradient GEMM of the second layer multiplies by the stored derivative
+    on the way out (no transcendentals in backward), and the weight-gradient kernels sum the bias gradients."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual=None, link=None):
@@ -1472,7 +1474,7 @@ class _GeluMLP(torch.autograd.Function):
                 db = None if bsink is not None else bbuf
             return dw, db
 
-        # second layer: dh = (gout W2) * gelu'(h), dW2 = gout^T g, db2 = colsum(gout)
+        # second layer: dh = (gout W2) * gelu'(pre-activation) (h holds that derivative), dW2 = gout^T g, db2 = colsum(gout)
         w2t, _ = SHADOWS.dgrad(w2, 1)  # [hd][n]
         dh = torch.empty_like(h)
         _launch_gather_gemm(gp, w2t, dh, None, None, M, hd, n, hd, n, one, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, gelu_of=h)
