@@ -1910,11 +1910,15 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
                     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[buf][ii]) : "v"(a) : "memory");
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[buf][ii]) : "v"(a), "n"(16 * BN * 2) : "memory");
                 }
-                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ii = 0; ii < GI; ++ii) {
+                    // the reads return in order (X fragments first, then the dY fragments one by one): a group of MFMAs
+                    // waits for its own dY fragment only, the later ones land under it
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (GI - 1 - ii)) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                     const int i = h * GI + ii;
                     const s16x8 yv = {ylo[buf][ii][0], ylo[buf][ii][1], ylo[buf][ii][2], ylo[buf][ii][3],
                                       yhi[buf][ii][0], yhi[buf][ii][1], yhi[buf][ii][2], yhi[buf][ii][3]};
