@@ -26,4 +26,6 @@ run r50_dp_resume      $S --distributed --model resnet50 --image-size 224 --batc
 run vit_dp_device      $S --distributed --model vit_b_16 --image-size 224 --batch-size 128 --dataset-length 2560 --device-data --optimizer adamw --learning-rate 0.0003
 run vit_dp_host        $S --distributed --model vit_b_16 --image-size 224 --batch-size 128 --dataset-length 2560 --num-workers 4 --optimizer adamw --learning-rate 0.0003
 run gpt2_dp            $S --distributed --model gpt2_medium --batch-size 8 --dataset-length 160 --optimizer adamw --learning-rate 0.0003 --watchdog-s 120
+run r50_det_finite     $S --distributed --model resnet50 --image-size 224 --batch-size 64 --dataset-length 1280 --num-workers 2 --optimizer sgd --deterministic --check-finite --keep-checkpoints 3 --checkpoint-path "${TMPDIR:-/tmp}/pdt_matrix_det.pt" --save-every 4
+PDT_FORCE_AUTOTUNE=1 run r50_autotune $S --distributed --model resnet50 --image-size 224 --batch-size 128 --dataset-length 2560 --device-data --optimizer sgd --bucket-mb auto
 echo ALL-OK
