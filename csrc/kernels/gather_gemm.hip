@@ -412,6 +412,13 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 // the per-channel scale / shift read from a table in LDS - followed by a second barrier, so each element is
 // transformed once per tile (doing it on the MFMA fragments would repeat the arithmetic in all four waves of a wave
 // row).  These launches are bound by their output stores; the extra LDS pass and barrier hide behind them.
+// 16 bytes per lane from `base + soff + voff` straight into LDS through a buffer instruction: `soff` is wave-uniform, a
+// lane whose `voff` lies beyond the descriptor's 2 GiB range reads nothing and has zeros written for it.
+__device__ __forceinline__ void buffer_load_lds_16(bf16* base, lds_void_t* dst, uint32_t voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int BK = GG_BK, bool PLAIN = false, bool PP = false, bool XF = false>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const GatherGemmArgs p) {
     constexpr int NW = WM * WN;
@@ -475,8 +482,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     // further down; a "tap" is then one K-step (dh = its first kernel row) and C = 64 makes it a single channel block.
     const int kchunk_a = p.tw ? ((kchunk >> 3) / (p.tw >> 3)) * p.Win * p.cs + (((kchunk >> 3) % (p.tw >> 3)) << 3) : kchunk;
     int ld_tile = first, ld_t = 0, ld_c0 = 0, ld_issued = 0, ld_slot = 0;
-    int a_pix[AI], a_h[AI], a_w[AI];
-    int b_off[BI];
+    // Gather loader (multi-tap launches): buffer instructions with LDS destination.  Per tile, a resource descriptor
+    // whose base is the input pixel of the tile's first row (minus the largest backward reach of a tap) and, per DMA
+    // piece, this lane's byte offset from it and its pixel's input coordinates.  A K-step adds a wave-uniform byte
+    // offset (tap displacement + channel block) in the instruction's scalar offset, so the issue sequence is the bounds
+    // test and one select per piece: a lane whose tap falls outside the image gets an offset beyond the descriptor's
+    // range and the hardware writes zeros for it - no page of zeros, no 64-bit address arithmetic per lane.
+    constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
+    bf16* ga_base = const_cast<bf16*>(p.A);  // (descriptor bases; the descriptors are formed where they are used)
+    bf16* gb_base = const_cast<bf16*>(p.B);
+    uint32_t a_lane[AI], b_lane[BI];
+    int a_h[AI], a_w[AI];
+    int halo = 0;  // elements: how far the most backward tap reaches in front of an output pixel's own input pixel
+    if constexpr (!PLAIN) {
+        for (int t = 0; t < p.T; ++t) halo = max(halo, -(p.tap_dh[t] * p.Win + p.tap_dw[t]) * p.cs);
+    }
     // First tile row of this wave's DMA piece i.  Plain ring: consecutive pieces.  Ping-pong: pieces 2i' and 2i'+1 of
     // staging unit i >> 1 (A: rows [64u, 64u + 64) of both wave rows; B: columns [32v, 32v + 32) of all four wave columns).
     auto row_a = [&](int i) {
@@ -495,29 +515,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             return (wave * BI + i) * PR;
         }
     };
+    auto pixel_in = [&](int m, int& ah, int& aw) -> size_t {
+        const uint32_t img = fastdiv(m, p.div_ab);
+        const uint32_t rem = m - img * (p.OA * p.OB);
+        const uint32_t a = fastdiv(rem, p.div_b);
+        const uint32_t b = rem - a * p.OB;
+        ah = a * p.istr;
+        aw = b * p.istr;
+        return static_cast<size_t>(img) * (p.Hin * p.Win) + static_cast<uint32_t>(ah * p.Win + aw);
+    };
     auto loader_tile = [&](int tile) {
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        int h0, w0;
+        const size_t pix0 = pixel_in(min(tile_m * BM, p.M - 1), h0, w0);  // (wave-uniform)
+        ga_base = const_cast<bf16*>(p.A) + (static_cast<ptrdiff_t>(pix0 * static_cast<uint32_t>(p.cs)) - halo);
+        gb_base = const_cast<bf16*>(p.B) + static_cast<size_t>(tile_n * BN) * p.ldb;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int m = tile_m * BM + row_a(i) + lrow;
+            // (one assignment per array element, outside the branch: stores to different elements in the two arms get
+            // merged into one store through a selected address, which keeps the arrays in scratch memory)
+            int ah = -(1 << 24), aw = 0;
+            uint32_t lane_off = OUT_OF_RANGE;
             if (m < p.M) {
-                const uint32_t img = fastdiv(m, p.div_ab);
-                const uint32_t rem = m - img * (p.OA * p.OB);
-                const uint32_t a = fastdiv(rem, p.div_b);
-                const uint32_t b = rem - a * p.OB;
-                a_pix[i] = img * (p.Hin * p.Win);
-                a_h[i] = a * p.istr;
-                a_w[i] = b * p.istr;
-            } else {
-                a_pix[i] = 0;
-                a_h[i] = -(1 << 24);
-                a_w[i] = 0;
+                const size_t pixel = pixel_in(m, ah, aw);
+                lane_off = (static_cast<uint32_t>(pixel - pix0) * static_cast<uint32_t>(p.cs) + kchunk_a) * 2u;
             }
+            a_lane[i] = lane_off;
+            a_h[i] = ah;
+            a_w[i] = aw;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const int n = tile_n * BN + row_b(i) + lrow;
-            b_off[i] = n < p.N ? n * p.ldb : -1;
+            const int r = row_b(i) + lrow;
+            b_lane[i] = tile_n * BN + r < p.N ? (static_cast<uint32_t>(r) * static_cast<uint32_t>(p.ldb) + kchunk) * 2u : OUT_OF_RANGE;
         }
     };
     // pieces [a_lo, a_hi) of the A tile and [b_lo, b_hi) of the B tile of the stage under the cursor
@@ -526,7 +557,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     // DMA requests of every K-step.
     int ld_dh = p.tap_dh[0], ld_dw = p.tap_dw[0], ld_wo = p.tap_woff[0];
     auto issue_pieces = [&](int a_lo, int a_hi, int b_lo, int b_hi) {
-        const int dh = ld_dh, dw = ld_dw, woff = ld_wo + ld_c0 + kchunk;
+        const int dh = ld_dh, dw = ld_dw;
+        const int a_soff = (halo + (dh * p.Win + dw) * p.cs + ld_c0) * 2;  // (wave-uniform, never negative)
+        const int b_soff = (ld_wo + ld_c0) * 2;
         bf16* sA = ring + ld_slot * STAGE;
         bf16* sB = sA + BM * BK;
 #pragma unroll
@@ -535,15 +568,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
             const int ih = a_h[i] + dh, iw = a_w[i] + dw;
             const bool ok = static_cast<unsigned>(ih) < static_cast<unsigned>(p.Hin) &&
                             static_cast<unsigned>(iw) < static_cast<unsigned>(p.Win);
-            const uint32_t off = static_cast<uint32_t>(a_pix[i] + ih * p.Win + iw) * p.cs + ld_c0 + kchunk_a;
-            const bf16* src = ok ? p.A + off : p.zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
+            buffer_load_lds_16(ga_base, (lds_void_t*)(sA + row_a(i) * BK), ok ? a_lane[i] : OUT_OF_RANGE, a_soff);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (i < b_lo || i >= b_hi) continue;
-            const bf16* src = b_off[i] >= 0 ? p.B + static_cast<uint32_t>(b_off[i] + woff) : p.zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)src, (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
+            buffer_load_lds_16(gb_base, (lds_void_t*)(sB + row_b(i) * BK), b_lane[i], b_soff);
         }
     };
     auto issue_stage = [&]() {
@@ -576,7 +606,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
     // the statistics, and past its last tile the loader re-reads tile 0, which nothing consumes.
     const char* a_base = nullptr;
     const char* b_base = nullptr;
-    uint32_t a_lane[AI], b_lane[BI];
+    uint32_t pa_lane[AI], pb_lane[BI];
     // output row m reads input pixel m (linear layers, stride-1 1x1 convolutions): no index arithmetic in the loader
     const bool a_identity = p.istr == 1 && p.OA == p.Hin && p.OB == p.Win;
     auto pixel_of = [&](int m) -> size_t {
@@ -597,12 +627,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int m = min(mt + row_a(i) + lrow, p.M - 1);
-            a_lane[i] = (static_cast<uint32_t>(pixel_of(m) - pix0) * static_cast<uint32_t>(p.C) + kchunk) * 2u;
+            pa_lane[i] = (static_cast<uint32_t>(pixel_of(m) - pix0) * static_cast<uint32_t>(p.C) + kchunk) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int n = min(nt + row_b(i) + lrow, p.N - 1) - nt;
-            b_lane[i] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(p.ldb) + kchunk) * 2u;
+            pb_lane[i] = (static_cast<uint32_t>(n) * static_cast<uint32_t>(p.ldb) + kchunk) * 2u;
         }
     };
     auto plain_pieces = [&](int a_lo, int a_hi, int b_lo, int b_hi) {
@@ -611,12 +641,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_ring_kernel(const Ga
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             if (i < a_lo || i >= a_hi) continue;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(a_base + a_lane[i]), (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(a_base + pa_lane[i]), (lds_void_t*)(sA + row_a(i) * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (i < b_lo || i >= b_hi) continue;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(b_base + b_lane[i]), (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t*)(b_base + pb_lane[i]), (lds_void_t*)(sB + row_b(i) * BK), 16, 0, 0);
         }
     };
     auto plain_issue = [&]() {
