@@ -2,7 +2,7 @@
 # MFMA / vector-ALU counters of the convolution kernels of some ResNet-50 layers: bench/layer_pmc.sh LAYER-FILTER [batch]
 set -e
 R=$PWD
-D=$R/gpurun_out/r3/layer_pmc
+D=$R/gpurun_out/layer_pmc
 mkdir -p $D
 export TMPDIR=/tmp
 cd /tmp
