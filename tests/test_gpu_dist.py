@@ -341,3 +341,25 @@ def test_bucket_autotune_runs_end_to_end_on_the_rccl_communicator(one_rank_group
     assert d is not None and d["bucket_mb"] > 0 and d["backward_ms"] > 0 and len(d["probe_us"]) == 5
     assert nb_b == d["buckets"]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant", ["plain", "bf16", "rs_ag"])
+def test_rank_body_of_the_multi_gpu_parity_test_as_one_gpu_rank(tmp_path, free_port, variant):
+    """`test_gpu_multi.py` needs two GPUs; its rank body runs here as a one-rank RCCL job (own communicator, bucket
+    collectives of world size 1, the bf16 wire's pack / unpack kernels, reduce-scatter + all-gather in place), so the
+    code the N-GPU run executes is known to be current on hardware."""
+    import torch.multiprocessing as mp
+
+    from dist_workers import dp_parity_worker
+
+    mp.spawn(dp_parity_worker, args=(1, free_port, str(tmp_path), True, variant), nprocs=1, join=True)
+    assert (tmp_path / f"ok_{variant}_0").exists()
+
+
+def test_rank_body_of_the_multi_gpu_recorded_step_test_as_one_gpu_rank(tmp_path, free_port):
+    import torch.multiprocessing as mp
+
+    from dist_workers import graphed_trainer_worker
+
+    mp.spawn(graphed_trainer_worker, args=(1, free_port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok_graph_0").exists()
