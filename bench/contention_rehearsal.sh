@@ -19,3 +19,10 @@ run "heavy resident $c workgroups at $gbps GB/s    " PDT_SELF_ALLREDUCE=1 PDT_RE
 done; done
 run "resident 32 at 50 GB/s, 32 CUs reserved      " PDT_SELF_ALLREDUCE=1 PDT_REHEARSE_CHANNELS=32 PDT_REHEARSE_GBPS=50 PDT_RESERVE_CUS=32
 run "no collective, 32 CUs reserved               " PDT_RESERVE_CUS=32
+# finer hand-out by the hardware's dispatcher: two workgroups per CU slot, each with half the tiles
+run "two rounds of workgroups, no collective       " PDT_GRID_ROUNDS=2 PDT_WGRAD_RING_TARGET_BLOCKS=512
+for gbps in 150 50; do for c in 16 32 64; do
+run "two rounds, heavy resident $c at $gbps GB/s      " PDT_GRID_ROUNDS=2 PDT_WGRAD_RING_TARGET_BLOCKS=512 PDT_SELF_ALLREDUCE=1 PDT_REHEARSE_HEAVY=1 PDT_REHEARSE_CHANNELS=$c PDT_REHEARSE_GBPS=$gbps
+done; done
+run "four rounds of workgroups, no collective      " PDT_GRID_ROUNDS=4 PDT_WGRAD_RING_TARGET_BLOCKS=1024
+run "four rounds, heavy resident 32 at 50 GB/s      " PDT_GRID_ROUNDS=4 PDT_WGRAD_RING_TARGET_BLOCKS=1024 PDT_SELF_ALLREDUCE=1 PDT_REHEARSE_HEAVY=1 PDT_REHEARSE_CHANNELS=32 PDT_REHEARSE_GBPS=50

@@ -1240,7 +1240,11 @@ static int launch_gather_gemm_ring_plain(const GatherGemmArgs& a, hipStream_t st
     }
     const int per_cu = static_cast<int>((160 * 1024) / lds);
     const long long tiles = static_cast<long long>(pdt_cdiv(a.M, BM)) * pdt_cdiv(a.N, BN);
-    const long long cap = static_cast<long long>(pdt_num_cus()) * per_cu;
+    // PDT_GRID_ROUNDS=k: k workgroups per CU slot, each with 1/k of the tiles.  The slots still hold one workgroup at a
+    // time, so the hardware's dispatcher hands the later workgroups to whichever CUs come free first - a CU held by a
+    // collective's workgroup loses 1/k of a share instead of a whole one, at the price of k - 1 more pipeline fills per CU.
+    static const int rounds = [] { const char* e = getenv("PDT_GRID_ROUNDS"); const int k = e ? atoi(e) : 1; return k >= 1 && k <= 16 ? k : 1; }();
+    const long long cap = static_cast<long long>(pdt_num_cus()) * per_cu * rounds;
     const int grid = static_cast<int>(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WM * WN * 64), lds, stream, a);
     return pdt_launch_status();
