@@ -642,23 +642,28 @@ PDT_API int pdt_bn_bwd_apply(const void* dout, const void* out, const void* y, c
 // ------------------------------------------------------------------------------------------------
 // Stem tail: out = maxpool3x3/s2/p1(relu(y*scale + shift)), idx = winning tap (0..8) per channel
 // ------------------------------------------------------------------------------------------------
+// HOIST: C/8 divides 256, so a thread's channel chunk is the same in every iteration and the constants stay in registers.
+template <bool HOIST>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ consts,
                                                                  bf16* __restrict__ out, uint8_t* __restrict__ idx,
                                                                  bf16* __restrict__ ywin, int NB, int H, int W, int C,
-                                                                 int Ho, int Wo) {
-    const int cvec = C >> 3;
-    const long long nvec = static_cast<long long>(NB) * Ho * Wo * cvec;
-    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
-        const int cv = static_cast<int>(v % cvec);
-        long long pix = v / cvec;
-        const int wo = static_cast<int>(pix % Wo);
-        pix /= Wo;
-        const int ho = static_cast<int>(pix % Ho);
-        const int n = static_cast<int>(pix / Ho);
-        const int c = cv << 3;
-        float sc[8], sh[8];
+                                                                 int Ho, int Wo, FastDiv div_wo, FastDiv div_ho, FastDiv div_cvec) {
+    const uint32_t cvec = C >> 3;
+    const uint32_t nvec = static_cast<uint32_t>(NB) * Ho * Wo * cvec;
+    float sc[8], sh[8];
+    auto load_consts = [&](int c) {
         load8f(consts + 2 * C + c, sc);
         load8f(consts + 3 * C + c, sh);
+    };
+    if (HOIST) load_consts(static_cast<int>(threadIdx.x & (cvec - 1)) << 3);
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < nvec; v += gridDim.x * 256u) {
+        const uint32_t pix = fastdiv(v, div_cvec);
+        const int c = static_cast<int>(v - pix * cvec) << 3;
+        const uint32_t t = fastdiv(pix, div_wo);
+        const int wo = static_cast<int>(pix - t * Wo);
+        const uint32_t n = fastdiv(t, div_ho);
+        const int ho = static_cast<int>(t - n * Ho);
+        if (!HOIST) load_consts(c);
         float best[8];
         int bi[8];
         bf16x8 yw;
@@ -696,9 +701,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
             if (e < 4) lo |= static_cast<uint32_t>(bi[e]) << (8 * e);
             else hi |= static_cast<uint32_t>(bi[e]) << (8 * (e - 4));
         }
-        *reinterpret_cast<bf16x8*>(out + v * 8) = o;
-        *reinterpret_cast<uint2*>(idx + v * 8) = make_uint2(lo, hi);
-        if (ywin != nullptr) *reinterpret_cast<bf16x8*>(ywin + v * 8) = yw;
+        const size_t ov = static_cast<size_t>(v) * 8;
+        *reinterpret_cast<bf16x8*>(out + ov) = o;
+        *reinterpret_cast<uint2*>(idx + ov) = make_uint2(lo, hi);
+        if (ywin != nullptr) *reinterpret_cast<bf16x8*>(ywin + ov) = yw;
     }
 }
 
@@ -708,10 +714,14 @@ PDT_API int pdt_bn_relu_maxpool_fwd(const void* y, const float* consts, void* ou
                                     int W, int C, void* stream) {
     if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return -1;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long long nvec = static_cast<long long>(NB) * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_grid(nvec)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    const int cvec = C / 8;
+    const long long nvec = static_cast<long long>(NB) * Ho * Wo * cvec;
+    if (nvec >= (1ll << 31)) return -1;
+    const bool hoist = cvec <= 256 && (cvec & (cvec - 1)) == 0;
+    auto kernel = hoist ? bn_relu_maxpool_fwd_kernel<true> : bn_relu_maxpool_fwd_kernel<false>;
+    hipLaunchKernelGGL(kernel, dim3(ew_grid(nvec)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16*>(y), consts, static_cast<bf16*>(out), static_cast<uint8_t*>(idx),
-                       static_cast<bf16*>(ywin), NB, H, W, C, Ho, Wo);
+                       static_cast<bf16*>(ywin), NB, H, W, C, Ho, Wo, make_fastdiv(Wo), make_fastdiv(Ho), make_fastdiv(cvec));
     return pdt_launch_status();
 }
 
