@@ -569,26 +569,46 @@ __global__ __launch_bounds__(256) void embedding_pos_fwd_kernel(const long long*
     }
 }
 
-// dst[r][c] += sum over b of g[b][row0 + r][c]  for r in [0, R): g is [B][S][D] bf16, dst is [R][D] fp32
+// dst[r][c] += sum over b of g[b][row0 + r][c]  for r in [0, R): g is [B][S][D] bf16, dst is [R][D] fp32.
+// gridDim.y slices of the batch, each adding its partial sum with atomics (one slice: a plain read-modify-write) - a
+// position table has only R D / 8 chunks, far fewer threads than the GPU holds, and the batch is the long axis.
 __global__ __launch_bounds__(256) void batch_rowsum_kernel(const bf16* __restrict__ g, float* __restrict__ dst, int B, int S, int D,
                                                           int row0, int R) {
     const int dvec = D >> 3;
-    const long long nvec = static_cast<long long>(R) * dvec;
-    for (long long v = blockIdx.x * 256ll + threadIdx.x; v < nvec; v += gridDim.x * 256ll) {
-        const int r = static_cast<int>(v / dvec);
-        const int c = static_cast<int>(v - static_cast<long long>(r) * dvec) << 3;
+    const int nvec = R * dvec;
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+    const long long bstride = static_cast<long long>(S) * D;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nvec; v += gridDim.x * 256) {
+        const int r = v / dvec;
+        const int c = (v - r * dvec) << 3;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         const bf16* src = g + (static_cast<long long>(row0 + r)) * D + c;
-        for (int b = 0; b < B; ++b) {
-            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(src + static_cast<long long>(b) * S * D);
+        int bb = b0;
+        for (; bb + 4 <= b1; bb += 4) {  // four independent loads in flight per lane
+            bf16x8 gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src + (bb + u) * bstride));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32(gv[u][e]);
+        }
+        for (; bb < b1; ++bb) {
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(src + bb * bstride);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32(gv[e]);
         }
         float* d = dst + static_cast<long long>(r) * D + c;
+        if (gridDim.y == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] += acc[e];
+            for (int e = 0; e < 8; ++e) d[e] += acc[e];
+        } else if (b0 < b1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) __hip_atomic_fetch_add(d + e, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -602,8 +622,15 @@ PDT_API int pdt_embedding_pos_fwd(const long long* ids, const float* w, const fl
 
 PDT_API int pdt_batch_rowsum(const void* g, float* dst, int B, int S, int D, int row0, int R, void* stream) {
     if (B <= 0 || S <= 0 || D <= 0 || (D % 8) != 0 || row0 < 0 || R <= 0 || row0 + R > S) return -1;
-    hipLaunchKernelGGL(batch_rowsum_kernel, dim3(ew_grid8(static_cast<long long>(R) * (D / 8))), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16*>(g), dst, B, S, D, row0, R);
+    const long long nvec = static_cast<long long>(R) * (D / 8);
+    if (nvec >= (1ll << 31)) return -1;
+    const int gx = ew_grid8(nvec);
+    // enough workgroups for four per CU; deterministic mode: one adder per element, in batch order
+    int gy = pdt_deterministic_flag ? 1 : (1024 + gx - 1) / gx;
+    if (gy > B / 8) gy = B / 8;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(batch_rowsum_kernel, dim3(gx, gy), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16*>(g), dst, B, S, D, row0, R);
     return pdt_launch_status();
 }
 
