@@ -1298,6 +1298,353 @@ static int launch_gather_gemm_ring(const GatherGemmArgs& a, hipStream_t stream) 
     return launch_gather_gemm_ring_epi<BM, BN, WM, WN, NS, 0, BK, PP>(a, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolution, stride 1, padding 1, 64 input and 64 output channels (forward and data gradient of the first
+// ResNet stage): the nine taps share one copy of the input rows in LDS.
+//
+// The tap-table kernels above fetch the [pixels][64] operand of every tap separately - nine trips of the same rows
+// through the L2 -> LDS path per output tile, with a K-step of 64 channels that lasts less than the path's latency, so
+// a two-stage ring cannot cover it (these layers ran at 0.5 PFLOP/s).  Here a workgroup owns a CONTIGUOUS range of
+// output rows and keeps a window of input rows in a circular LDS buffer: output row m needs input rows m + dh W + dw,
+// i.e. the rows [m0 - W - 1, m0 + 256 + W] for a tile of 256, which overlap the next tile's by all but 256 rows, so
+// every input row is fetched once per workgroup.  The tap is a shift of the fragment's row address; a tap that falls
+// outside the image (the shifted row then belongs to the neighbouring image row or image) reads a chunk of zeros
+// instead.  The 3x3x64x64 weights (72 KB) stay in LDS for the whole launch.
+//
+//   LDS: [560 input rows of 128 B, circular][128 B of zeros][9 taps x 64 x 64 weights][8 waves x 16 x 64 staging]
+//   tile of 256 output rows, 8 waves x (32 rows x 64 channels), 9 taps x 16 MFMAs per wave
+//   refill of the window for the next tile in three portions (128, 64, 64 rows) as the taps of the current tile retire
+//   the rows they were the last to need: taps are worked off in the order dh = -1, 0, +1, and a workgroup barrier
+//   after each dh separates the last reads of a row from the DMA that overwrites it.
+// Needs 24 <= W <= 63 (the halo W + 1 fits the 64 rows kept on either side; the refill schedule assumes that the
+// dh = +1 taps read nothing below row m0 + 16).
+// ------------------------------------------------------------------------------------------------
+constexpr int HALO_CAP = 560;                         // rows of the circular input buffer
+constexpr int HALO_Z_OFF = HALO_CAP * 128;            // 128 bytes of zeros
+constexpr int HALO_B_OFF = HALO_Z_OFF + 128;          // weights: [9][64 output channels][64 input channels]
+constexpr int HALO_EPI_OFF = HALO_B_OFF + 9 * 8192;   // per-wave staging rows of the epilogue
+constexpr int HALO_LDS = HALO_EPI_OFF + 8 * 2048;
+static_assert(HALO_LDS <= 160 * 1024, "the halo kernel's buffers fit the LDS of a CU");
+
+// EPI 0: forward statistics of the stored values (if p.stats);  EPI 4: BatchNorm-backward sums with the ReLU mask
+// recomputed from bn_y (see gather_gemm_ring_kernel)
+template <int EPI>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs p, const int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int total_tiles = (p.M + 255) >> 8;
+    const int tile_begin = blockIdx.x * tiles_per_wg;
+    const int ntiles = min(tiles_per_wg, total_tiles - tile_begin);
+    const int m_begin = tile_begin << 8;
+    const int W = p.Win, H = p.Hin;
+
+    // ---- loader: 1 KB pieces (8 rows of 128 bytes); lane -> (row, physical chunk), fetching the chunk the swizzle puts there
+    const int lrow = lane >> 3;
+    const int kchunk = ((lane & 7) ^ lrow) << 3;
+    {   // weights, in the order the taps are worked off: tap k = (k / 3 - 1, k % 3 - 1); wave w fetches output channels 8w ..
+        bf16* bbase = const_cast<bf16*>(p.B);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            int woff = 0;
+            for (int t = 0; t < 9; ++t)
+                if (p.tap_dh[t] == k / 3 - 1 && p.tap_dw[t] == k % 3 - 1) woff = p.tap_woff[t];
+            const uint32_t voff = static_cast<uint32_t>((8 * wave + lrow) * p.ldb + woff + kchunk) * 2u;
+            buffer_load_lds_16(bbase, (lds_void_t*)(smem + HALO_B_OFF + k * 8192 + wave * 1024), voff, 0);
+        }
+    }
+    // input rows are addressed relative to row m_begin - 64, which sits at physical row 0
+    bf16* abase = const_cast<bf16*>(p.A) + (static_cast<ptrdiff_t>(m_begin) - 64) * p.cs;
+    auto issue_rows = [&](int rel0, int phys0) {  // 8 rows from relative row rel0 (a multiple of 8) to physical row phys0
+        const int rel = rel0 + lrow;
+        const int m = m_begin - 64 + rel;
+        const bool ok = m >= 0 && m < p.M;
+        const uint32_t voff = ok ? static_cast<uint32_t>(rel * p.cs + kchunk) * 2u : OUT_OF_RANGE;
+        buffer_load_lds_16(abase, (lds_void_t*)(smem + phys0 * 128), voff, 0);
+    };
+    int ld_rel = 0, ld_phys = 0;  // the next row to fetch (relative / physical); both multiples of 8
+    auto refill = [&](int pieces_per_wave) {  // 8 waves x pieces x 8 rows
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= pieces_per_wave) continue;
+            const int q = (wave + 8 * k) * 8;
+            int ph = ld_phys + q;
+            ph = ph >= HALO_CAP ? ph - HALO_CAP : ph;
+            issue_rows(ld_rel + q, ph);
+        }
+        ld_rel += pieces_per_wave * 64;
+        ld_phys += pieces_per_wave * 64;
+        ld_phys = ld_phys >= HALO_CAP ? ld_phys - HALO_CAP : ld_phys;
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) issue_rows((wave + 8 * k) * 8, (wave + 8 * k) * 8);  // rows [m_begin - 64, m_begin + 320)
+    ld_rel = ld_phys = 384;
+    if (tid < 32) *reinterpret_cast<uint32_t*>(smem + HALO_Z_OFF + 4 * tid) = 0u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- fragment addressing
+    // weights: output channel 16 j + lr, chunk (2 kk' ...): byte offset of the kk = 0 fragment of j = 0, tap 0
+    const uint32_t b_off0 = HALO_B_OFF + lr * 128 + ((lg ^ (lr & 7)) << 4);
+    // ---- epilogue state
+    const int ech = lane & 7, erow = lane >> 3;
+    bf16* epi = reinterpret_cast<bf16*>(smem + HALO_EPI_OFF + wave * 2048);
+    float s1[8], s2[8], f0f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = f0f[e] = 0.f;
+    float fcnt = 0.f;
+    bool f0_fresh = true;
+    float msc[8], msh[8];
+    if constexpr (EPI == 4) {
+        *reinterpret_cast<f32x4*>(msc) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * 64 + ech * 8);
+        *reinterpret_cast<f32x4*>(msc + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 2 * 64 + ech * 8 + 4);
+        *reinterpret_cast<f32x4*>(msh) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * 64 + ech * 8);
+        *reinterpret_cast<f32x4*>(msh + 4) = *reinterpret_cast<const f32x4*>(p.bn_consts + 3 * 64 + ech * 8 + 4);
+    }
+    const bool want_stats = EPI == 4 || p.stats != nullptr;
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][4];
+    int base_phys = 0;  // physical row of input row m0 - 64
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int m0 = m_begin + (ti << 8);
+        const bool more = ti + 1 < ntiles;
+        if (more) refill(2);
+        // this lane's two fragment rows: which taps stay inside the image, and the row's place in the buffer
+        bool hm[2], hp[2], wm_[2], wp[2];
+        int rowp[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t r = static_cast<uint32_t>(m0 + 32 * wave + 16 * i + lr);
+            const uint32_t img = fastdiv(r, p.div_ab);
+            const uint32_t rem = r - img * (p.OA * p.OB);
+            const uint32_t h = fastdiv(rem, p.div_b);
+            const uint32_t w = rem - h * p.OB;
+            hm[i] = h > 0;
+            hp[i] = static_cast<int>(h) < H - 1;
+            wm_[i] = w > 0;
+            wp[i] = static_cast<int>(w) < W - 1;
+            rowp[i] = base_phys + 64 + 32 * wave + 16 * i + lr;
+        }
+        // Fragments of tap k + 1 are requested before the MFMAs of tap k are issued (two register sets), so a tap costs
+        // one counted wait on the LDS queue instead of one per fragment.  Tap 3 is requested in front of the first
+        // barrier: its rows (up to m0 + 254) are in place since the tile began, and the barriers only keep the DMA that
+        // OVERWRITES rows behind the last wave that reads them.
+        bf16x8 fa[2][2][2], fb[2][2][4];
+        auto load = [&](auto kc, auto bc) {
+            constexpr int k = decltype(kc)::value, buf = decltype(bc)::value;
+            constexpr int dh = k / 3 - 1, dw = k % 3 - 1;
+            const int delta = dh * W + dw;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = (dh < 0 ? hm[i] : (dh > 0 ? hp[i] : true)) && (dw < 0 ? wm_[i] : (dw > 0 ? wp[i] : true));
+                int ph = rowp[i] + delta;
+                ph = ph >= HALO_CAP ? ph - HALO_CAP : ph;
+                uint32_t a0 = static_cast<uint32_t>(ph * 128 + ((lg ^ (ph & 7)) << 4));
+                a0 = ok ? a0 : static_cast<uint32_t>(HALO_Z_OFF);
+                fa[buf][0][i] = *reinterpret_cast<const bf16x8*>(smem + a0);
+                fa[buf][1][i] = *reinterpret_cast<const bf16x8*>(smem + (a0 ^ 64u));  // channels 32 .. 63: chunk index + 4
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fb[buf][0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off0 + k * 8192 + j * 2048);
+                fb[buf][1][j] = *reinterpret_cast<const bf16x8*>(smem + (b_off0 ^ 64u) + k * 8192 + j * 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma = [&](auto kc, auto bc) {
+            constexpr int k = decltype(kc)::value, buf = decltype(bc)::value;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][kk][j], fa[buf][kk][i],
+                                                                            (k == 0 && kk == 0) ? zero4 : acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using std::integral_constant;
+        constexpr integral_constant<int, 0> B0{};
+        constexpr integral_constant<int, 1> B1{};
+        load(integral_constant<int, 0>{}, B0);
+        load(integral_constant<int, 1>{}, B1);
+        mma(integral_constant<int, 0>{}, B0);
+        load(integral_constant<int, 2>{}, B0);
+        mma(integral_constant<int, 1>{}, B1);
+        load(integral_constant<int, 3>{}, B1);
+        mma(integral_constant<int, 2>{}, B0);
+        // The last portion of the previous tile's refill (rows that the taps from number 5 on read) has landed: what this
+        // wave has issued since are the previous tile's 4 stores and, if there is a next tile, this tile's first portion
+        // (2 requests).  (Only the launch's very last tile can store fewer rows, and nothing is refilled after it.)
+        if (more) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // and nobody reads rows below m0 - 1 any more
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        // BatchNorm-backward sums: this lane's pre-normalisation activations of the tile, requested six taps before
+        // their use (rows beyond M read the last row)
+        u32x4 yraw[2][2];
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int m = min(m0 + 32 * wave + 16 * i + ps * 8 + erow, p.M - 1);
+                    const bf16* q = p.bn_y + static_cast<size_t>(static_cast<uint32_t>(m)) * static_cast<uint32_t>(p.ldo) + ech * 8;
+                    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(yraw[i][ps]) : "v"(q) : "memory");
+                }
+        }
+        if (more) refill(1);
+        load(integral_constant<int, 4>{}, B0);
+        mma(integral_constant<int, 3>{}, B1);
+        load(integral_constant<int, 5>{}, B1);
+        mma(integral_constant<int, 4>{}, B0);
+        load(integral_constant<int, 6>{}, B0);
+        mma(integral_constant<int, 5>{}, B1);
+        asm volatile("s_barrier" ::: "memory");  // nobody reads rows below m0 + W - 1 any more
+        if (more) refill(1);
+        load(integral_constant<int, 7>{}, B1);
+        mma(integral_constant<int, 6>{}, B0);
+        load(integral_constant<int, 8>{}, B0);
+        mma(integral_constant<int, 7>{}, B1);
+        mma(integral_constant<int, 8>{}, B0);
+        // All but the last portion of the next tile's rows (and bn_y) have landed - waited for here, in front of this
+        // tile's stores, so that the wait never covers a store.  The last portion (one request per wave, three taps old)
+        // holds rows that only the taps behind the next tile's first barrier read: it is awaited there.
+        if (more) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue: 16 rows at a time -> bf16 -> wave-private LDS rows -> 16-byte row segments (staging layout as in
+        // gather_gemm_ring_kernel)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = j * 16 + lg * 4;
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(acc[i][j][e]);
+                *reinterpret_cast<bf16x4*>(epi + lr * 64 + ((((nl >> 3) ^ lr) & 7) << 3) + ((nl ^ (lr >> 1)) & 4)) = v;
+            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int row = ps * 8 + erow;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(epi + row * 64 + (((ech ^ row) & 7) << 3));
+                if (ps == 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+                if constexpr (EPI == 0) {
+                    if (i == 0 && ps == 0 && f0_fresh) {  // the lane's pivot: the first values it sees (see the ring kernel)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f0f[e] = bf16_to_f32(v[e]);
+                        f0_fresh = false;
+                    }
+                }
+                const int m = m0 + 32 * wave + 16 * i + row;
+                if (m < p.M) {
+                    bf16* dst = p.Out + static_cast<size_t>(static_cast<uint32_t>(m)) * static_cast<uint32_t>(p.ldo) + ech * 8;
+                    if (p.out_nt) {
+                        asm volatile("" ::: "memory");
+                        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
+                        asm volatile("" ::: "memory");
+                    } else {
+                        *reinterpret_cast<bf16x8*>(dst) = v;
+                    }
+                    if constexpr (EPI == 4) {
+                        const bf16x8 yv = __builtin_bit_cast(bf16x8, yraw[i][ps]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float y = bf16_to_f32(yv[e]);
+                            const float dz = (y * msc[e] + msh[e]) > 0.f ? bf16_to_f32(v[e]) : 0.f;
+                            s1[e] += dz;
+                            s2[e] += dz * y;
+                        }
+                    } else if (want_stats) {
+                        fcnt += 1.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = bf16_to_f32(v[e]) - f0f[e];
+                            s1[e] += f;
+                            s2[e] += f * f;
+                        }
+                    }
+                }
+            }
+        }
+        base_phys += 256;
+        base_phys = base_phys >= HALO_CAP ? base_phys - HALO_CAP : base_phys;
+        asm volatile("s_barrier" ::: "memory");  // every wave is done with this tile's rows, and everybody's refill has landed
+    }
+
+    // ---- the workgroup's sums -> one of the launch's accumulator slots
+    if (!want_stats) return;
+    const int ncol = ech * 8;
+    if constexpr (EPI == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float P = p.pivot != nullptr ? p.pivot[ncol + e] : 0.f;
+            const float dl = f0f[e] - P;
+            s2[e] += dl * (2.f * s1[e] + fcnt * dl);
+            s1[e] += fcnt * dl;
+            if (p.pivot != nullptr && lane < 8) p.stats[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * 64 + ncol + e] = P;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s1[e] += __shfl_xor(s1[e], o, 64);
+            s2[e] += __shfl_xor(s2[e], o, 64);
+        }
+    }
+    if (lane < 8) {
+        float* slot = p.stats + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * p.stat_rows * 64;
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s2[e] = (s2[e] - p.bn_consts[ncol + e] * s1[e]) * p.bn_consts[64 + ncol + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __hip_atomic_fetch_add(slot + ncol + e, s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(slot + 64 + ncol + e, s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the launch is a 3x3 / stride 1 / padding 1 convolution of 64 -> 64 channels in the form conv3x3_halo_kernel handles
+static bool conv3x3_halo_applies(const GatherGemmArgs& a) {
+    static const bool enabled = std::getenv("PDT_CONV3X3_HALO") == nullptr || std::atoi(std::getenv("PDT_CONV3X3_HALO")) != 0;  // (A/B switch)
+    if (!enabled || a.tw != 0 || a.T != 9 || a.C != 64 || a.N != 64 || a.cs != 64 || a.ldo != 64) return false;
+    if (a.istr != 1 || a.ostr != 1 || a.oph != 0 || a.opw != 0) return false;
+    if (a.OA != a.Hin || a.OB != a.Win || a.Hout != a.Hin || a.Wout != a.Win || a.Win < 24 || a.Win > 63) return false;
+    if (a.bias != nullptr || a.addend != nullptr || a.act != 0 || a.xf != nullptr || a.out_nt > 1) return false;
+    if (a.bn_y != nullptr && (a.bn_bits != nullptr || a.bn_y2 != nullptr || a.stats == nullptr || a.bn_consts == nullptr || a.stat_rows != 3))
+        return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int dh = a.tap_dh[t], dw = a.tap_dw[t];
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1 || a.tap_woff[t] < 0 || a.tap_woff[t] + 64 > a.ldb) return false;
+        seen |= 1u << ((dh + 1) * 3 + dw + 1);
+    }
+    return seen == 0x1ffu;
+}
+
+static int launch_conv3x3_halo(const GatherGemmArgs& a, hipStream_t stream) {
+    const int total = pdt_cdiv(a.M, 256);
+    const int cus = pdt_num_cus();
+    const int per = pdt_cdiv(total, cus);
+    const int grid = pdt_cdiv(total, per);
+    // 32-bit byte offsets from the workgroup's first row
+    if ((static_cast<long long>(per) * 256 + 1024) * 128 >= (1ll << 31)) return -1;
+    auto kernel = a.bn_y != nullptr ? conv3x3_halo_kernel<4> : conv3x3_halo_kernel<0>;
+    static bool configured[2] = {false, false};
+    const int which = a.bn_y != nullptr ? 1 : 0;
+    if (!configured[which]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured[which] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), HALO_LDS, stream, a, per);
+    return pdt_launch_status();
+}
+
 // Outputs of at least this many bytes are written with non-temporal stores by the ring kernels.  A negative value is a
 // measurement aid: the ring kernels then skip the output store altogether (what the epilogue's stores cost a launch).
 static long long g_out_nt_bytes = 64ll << 20;
@@ -1374,6 +1721,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
     } else if (smallc) {
         return N <= 64 ? launch_gather_gemm<128, 64, 4, 1, true>(a, s) : launch_gather_gemm<128, 128, 2, 2, true>(a, s);
     }
+    if ((tile == 14 || tile == 15) && conv3x3_halo_applies(a)) return launch_conv3x3_halo(a, s);
     switch (tile) {
         case 0: return launch_gather_gemm<128, 128, 2, 2>(a, s);
         case 1: return launch_gather_gemm<128, 64, 4, 1>(a, s);

@@ -98,6 +98,14 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
     # the 3-channel stem ("packed rows": a K-step spans two kernel rows), odd size so the last tile is partial and the
     # last image's last output row reaches the spare row behind the padded input
     test_conv_forward_backward(hip, 3, 3, 64, 7, 2, 3, 61)
+    if tile == 15:
+        # 3x3 / stride 1 / 64 -> 64 channels with 24 <= W <= 63 runs on the kernel that shares the input rows between the
+        # taps: the narrowest and widest images it takes, the ResNet size, and enough tiles per workgroup (more than 256
+        # tiles) for the circular row buffer to wrap several times
+        test_conv_forward_backward(hip, 7, 64, 64, 3, 1, 1, 24)
+        test_conv_forward_backward(hip, 3, 64, 64, 3, 1, 1, 63)
+        test_conv_forward_backward(hip, 64, 64, 64, 3, 1, 1, 56)
+        test_conv_forward_backward(hip, 5, 64, 64, 3, 1, 1, 23)  # (one too narrow: the tap-table kernel)
 
 
 @pytest.mark.parametrize("tile", [13, 16])
@@ -746,7 +754,8 @@ def test_bn_backward_sums_from_the_dgrad_epilogue_match_the_separate_reduction(h
     (ring kernels only).  Gradients must equal those of the path where BatchNorm reduces by itself."""
     torch.manual_seed(12)
     dev = _dev()
-    cases = [(80, 128, 256, 1, 1, 0, 56), (300, 128, 128, 3, 2, 1, 56), (70, 64, 64, 3, 1, 1, 56)]  # rows enough for ring kernels
+    cases = [(80, 128, 256, 1, 1, 0, 56), (300, 128, 128, 3, 2, 1, 56), (70, 64, 64, 3, 1, 1, 56),
+             (140, 64, 64, 3, 1, 1, 56)]  # rows enough for ring kernels; the last one for the shared-rows 3x3 kernel
     real_reduce, real_can = hip._bn_bwd_reduce, hip._dgrad_can_fuse_stats
     for nb, cin, cout, k, stride, pad, hw in cases:
         y = hip.to_device_layout(torch.randn(nb, cin, hw, hw, device=dev))
