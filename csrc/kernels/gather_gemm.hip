@@ -2454,6 +2454,212 @@ static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t strea
     return pdt_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 / padding 1 / 64 -> 64 convolution, input rows shared between the nine taps.
+//
+// The tap-table kernel above stages the [64 pixels][64] input operand of every tap separately (nine trips through the
+// L2 -> LDS path) and needs three 256-column tiles for the 576 columns, each re-reading dY.  Here the reduction runs
+// over PADDED pixel indices q = (img (H + 2) + hp) (W + 2) + wp, as if every image had a one-pixel border: dY and X
+// are laid out in LDS in that numbering, border positions hold zeros (the DMA's range check writes them), and tap
+// (dh, dw) of pixel q is simply row q + dh (W + 2) + dw of the same array - never outside the image's padded grid, so
+// there is no bounds logic in the main loop at all; a border position contributes nothing because its dY row is zero.
+// The price is (H + 2)(W + 2) / (H W) - 1 more K-steps (7 % at 56 x 56).
+//
+//   workgroup = one contiguous range of padded pixels (a split), all 64 x 576 columns: 8 waves as 2 (32 output
+//   channels) x 4 (9 column blocks of 16 = consecutive (tap, channel quarter) pairs), 72 accumulator registers
+//   LDS: X rows in a ring of eight 64-row blocks, dY in a ring of four 64-row stages
+//   per K-step of 64 pixels: one barrier, 3 DMA requests per wave (64 new X rows six blocks ahead, dY three steps ahead)
+// ------------------------------------------------------------------------------------------------
+constexpr int WH_X_BYTES = 640 * 128;  // X rows: a ring of eight 64-row blocks, blocks 0 and 1 mirrored behind block 7
+constexpr int WH_LDS = WH_X_BYTES + 4 * 8192;
+
+__global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, const int P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int H = p.Hin, W = p.Win, Wp = W + 2, HpWp = (H + 2) * Wp, HW = H * W;
+    const int split = blockIdx.x;
+    const int ps = split * p.m_per_split, pe = min(P, ps + p.m_per_split);  // (ps is a multiple of 64)
+    const int nsteps = (pe - ps + 63) >> 6;
+    const int blk0 = ps >> 6;
+    // 32-bit byte offsets from the first pixel of the image the range starts in
+    const int img_lo = max(ps - 64, 0) / HpWp;
+    bf16* xbase = const_cast<bf16*>(p.X) + static_cast<size_t>(img_lo) * HW * 64;
+    bf16* ybase = const_cast<bf16*>(p.dY) + static_cast<size_t>(img_lo) * HW * p.ldy;
+
+    // ---- loader: 1 KB pieces of 8 rows; lane -> (row, physical chunk); 32-byte units are XOR-ed with (row >> 1) & 3
+    const int lrow = lane >> 3, pc = lane & 7;
+    // element offset of padded pixel q from the base pixel, or -1 for a border position / a pixel outside the tensor
+    auto pixel_of = [&](int q) -> int {
+        if (q < 0 || q >= P) return -1;
+        const uint32_t img = fastdiv(static_cast<uint32_t>(q), p.div_ab);
+        const uint32_t rem = static_cast<uint32_t>(q) - img * HpWp;
+        const uint32_t hp = fastdiv(rem, p.div_b);
+        const uint32_t wp = rem - hp * Wp;
+        if (hp - 1u >= static_cast<uint32_t>(H) || wp - 1u >= static_cast<uint32_t>(W)) return -1;
+        return (static_cast<int>(img) - img_lo) * HW + static_cast<int>(hp - 1u) * W + static_cast<int>(wp - 1u);
+    };
+    // X block b = padded rows [ps + 64 (b - 1), ps + 64 b), at ring position (blk0 + b - 1) mod 8.  The window of a K-step
+    // is three consecutive blocks; so that it never wraps (which would put a wrap test into every fragment address), ring
+    // positions 0 and 1 exist a second time behind position 7.  Every block is requested twice - the second request
+    // goes to the mirror position if there is one and to the same place otherwise - so that a K-step always issues the
+    // same number of requests (the counted waits below rely on that).
+    auto issue_x = [&](int b) {
+        const int pos = (blk0 + b - 1) & 7;
+        const int q = ps + 64 * (b - 1) + 8 * wave + lrow;
+        const int chunk = (((pc >> 1) ^ ((q >> 1) & 3)) << 1) | (pc & 1);
+        const int m = pixel_of(q);
+        const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * 64 + chunk * 8) * 2u : OUT_OF_RANGE;
+        char* dst = smem + (64 * pos + 8 * wave) * 128;
+        buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
+        buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 2 ? 512 * 128 : 0)), voff, 0);
+    };
+    auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + 64 ks, + 64); rows beyond the split are zeros
+        const int q = ps + 64 * ks + 8 * wave + lrow;
+        const int chunk = (((pc >> 1) ^ ((q >> 1) & 3)) << 1) | (pc & 1);
+        const int m = q < pe ? pixel_of(q) : -1;
+        const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
+        buffer_load_lds_16(ybase, (lds_void_t*)(smem + WH_X_BYTES + (ks & 3) * 8192 + wave * 1024), voff, 0);
+    };
+    // K-step ks reads X blocks ks, ks + 1, ks + 2 and dY stage ks.  Issue order (fixed, so that the counted wait of a
+    // K-step - "all but the last six requests" - covers what it reads): X0 X1 X2 Y0 X3 Y1 X4 Y2 X5, then in K-step ks:
+    // X(ks + 6), Y(ks + 3)  (an X block is two requests).
+    issue_x(0); issue_x(1); issue_x(2); issue_y(0); issue_x(3); issue_y(1); issue_x(4); issue_y(2); issue_x(5);
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- transposed fragment reads (see wgrad_ring_body): lane (16 g + 4 q4 + pp) reads 4 columns of row 4 g + q4
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_void_t*)smem));
+    const int krow = 4 * g + q4;  // row inside a 32-pixel slice (+ 16 for the second read of a fragment)
+    uint32_t y_off[2];  // dY fragments of this wave's two blocks of 16 output channels, slice 0 of stage 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) y_off[i] = lds0 + WH_X_BYTES + static_cast<uint32_t>(krow * 64 + (((2 * wr + i) ^ ((krow >> 1) & 3)) << 4) + 4 * pp) * 2u;
+    // This wave's column blocks: block 9 wc + j = (tap (9 wc + j) / 4, channels 16 ((9 wc + j) % 4) ..).  The fragment
+    // of tap (dh, dw) is the fragment of the rows shifted by dh (W + 2) + dw; a K-step starts at a multiple of 64 rows, so
+    // a lane's offset from the window's first row - swizzle included - is the same in every K-step.
+    uint32_t x_off[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int cb = 9 * wc + j, tap = cb >> 2;
+        const int r = krow + (tap / 3 - 1) * Wp + (tap % 3 - 1);  // relative to the K-step's first pixel; >= -59
+        x_off[j] = lds0 + static_cast<uint32_t>((64 + r) * 128 + (((cb & 3) ^ ((r >> 1) & 3)) << 5) + 8 * pp);
+    }
+
+    for (int ks = 0; ks < nsteps; ++ks) {
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        issue_x(ks + 6);
+        issue_y(ks + 3);
+        const uint32_t xs = static_cast<uint32_t>(((blk0 + ks - 1) & 7) * 8192);  // the window's first row (block ks)
+        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 8192);
+        s16x4 ylo[2][2], yhi[2][2], xlo[2][3][2], xhi[2][3][2];  // [slice][...]; X: [buffer][block in group][slice]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t a = y_off[i] + ys;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[0][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yhi[0][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(ylo[1][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yhi[1][i]) : "v"(a) : "memory");
+        }
+        auto read_x = [&](const int gr, const int buf) {  // (constants after inlining)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const uint32_t a = x_off[gr * 3 + jj] + xs;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[buf][jj][0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xhi[buf][jj][0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(xlo[buf][jj][1]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(xhi[buf][jj][1]) : "v"(a) : "memory");
+            }
+        };
+        auto mma = [&](const int gr, const int buf) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const s16x8 yv = {ylo[kk][i][0], ylo[kk][i][1], ylo[kk][i][2], ylo[kk][i][3],
+                                      yhi[kk][i][0], yhi[kk][i][1], yhi[kk][i][2], yhi[kk][i][3]};
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+                        const s16x8 xv = {xlo[buf][jj][kk][0], xlo[buf][jj][kk][1], xlo[buf][jj][kk][2], xlo[buf][jj][kk][3],
+                                          xhi[buf][jj][kk][0], xhi[buf][jj][kk][1], xhi[buf][jj][kk][2], xhi[buf][jj][kk][3]};
+                        acc[i][gr * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
+                                                                                     acc[i][gr * 3 + jj], 0, 0, 0);
+                    }
+                }
+        };
+        read_x(0, 0);
+        read_x(1, 1);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");  // the dY fragments and the first group are back
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(2, 0);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing requests
+
+    // D[n][column]: lane holds output channels (lane >> 4) * 4 + e of its block, column lane & 15
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int cb = 9 * wc + j, tap = cb >> 2;
+        int woff = 0;
+        for (int t = 0; t < 9; ++t)
+            if (p.tap_dh[t] == tap / 3 - 1 && p.tap_dw[t] == tap % 3 - 1) woff = p.tap_woff[t];
+        const int col = woff + (cb & 3) * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = (2 * wr + i) * 16 + (lane >> 4) * 4 + e;
+                __hip_atomic_fetch_add(p.dW + static_cast<size_t>(split) * p.split_stride + static_cast<size_t>(n) * p.ldw + col, acc[i][j][e],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+}
+
+// tile 18: the launch must be the 3x3 / stride 1 / 64 -> 64 form; `splits` workgroups, one range of padded pixels each
+static int launch_wgrad3x3_halo(WgradArgs a, int splits, hipStream_t stream) {
+    if (a.T != 9 || a.C != 64 || a.N != 64 || a.istr != 1 || a.OA != a.Hin || a.OB != a.Win || a.Win > 61 || a.Win < 1 || a.tw != 0 ||
+        a.xf != nullptr || a.dbias != nullptr || (a.M % (a.Hin * a.Win)) != 0)
+        return -1;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int dh = a.tap_dh[t], dw = a.tap_dw[t];
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1 || a.tap_woff[t] < 0 || a.tap_woff[t] + 64 > a.ldw) return -1;
+        seen |= 1u << ((dh + 1) * 3 + dw + 1);
+    }
+    if (seen != 0x1ffu) return -1;
+    const int Wp = a.Win + 2, HpWp = (a.Hin + 2) * Wp;
+    const long long P = static_cast<long long>(a.M / (a.Hin * a.Win)) * HpWp;
+    if (P >= (1ll << 31) - 1024) return -1;
+    int kps = pdt_cdiv(P, splits);
+    kps = pdt_cdiv(kps, 64) * 64;
+    const int grid = pdt_cdiv(P, kps);
+    if ((static_cast<long long>(kps) + 2ll * HpWp + 1024) * (a.ldy > 64 ? a.ldy : 64) * 2 >= (1ll << 31)) return -1;
+    a.m_per_split = kps;
+    a.div_ab = make_fastdiv(HpWp);
+    a.div_b = make_fastdiv(Wp);
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured = true;
+    }
+    hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3(grid), dim3(512), WH_LDS, stream, a, static_cast<int>(P));
+    return pdt_launch_status();
+}
+
 static bool wgrad_is_plain(const WgradArgs& a) {
     return a.T == 1 && a.tap_dh[0] == 0 && a.tap_dw[0] == 0 && a.istr == 1 && a.OA == a.Hin && a.OB == a.Win;
 }
@@ -2580,7 +2786,10 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
         ++wgrad_npending;
         return 0;
     }
-    if (tile == 15) {
+    if (tile == 18) {
+        if (smallc || wgrad_grouping) return -1;
+        return launch_wgrad3x3_halo(a, splits, s);
+    } else if (tile == 15) {
         return launch_wgrad_ring<64, 256, 2, 4, 3, 1>(a, gy, s);
     } else if (smallc) {
         constexpr int BT = 64;

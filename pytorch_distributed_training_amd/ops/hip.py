@@ -606,6 +606,10 @@ WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "
 # Single-tap 256x256 weight gradients run on the ping-pong schedule (tile 17: the two wave rows of a workgroup alternate
 # between MFMA and LDS / DMA phases, as in the forward GEMM); 0 switches it off.
 WGRAD_PP = int(_os.environ.get("PDT_WGRAD_PP", "1"))
+# 3x3 / stride 1 / 64 -> 64 weight gradients on the kernel that shares the input rows between the taps (tile 18); 0: the
+# tap-table ring kernel
+WGRAD_HALO = int(_os.environ.get("PDT_WGRAD_HALO", "1"))
+_TAPS_3X3 = sorted((i, j) for i in (-1, 0, 1) for j in (-1, 0, 1))
 
 
 def _wgrad_splits(M: int, N: int, C: int, ntaps: int, bn: int, bc: Optional[int] = None, target: Optional[int] = None) -> int:
@@ -672,7 +676,13 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         tile = 14  # 256 x 64
     if tile == 16 and WGRAD_PP and len(taps) == 1 and xf is None:
         tile = 17  # (the launcher falls back to 16 when the tap is not the identity mapping)
-    if tile >= 10:
+    if (WGRAD_HALO and tile == 13 and not smallc and len(taps) == 9 and C == 64 and N == 64 and istr == 1 and OA == Hin
+            and OB == Win and Win <= 61 and xf is None and dbias is None and M >= 64 * _num_cus()
+            and sorted((t[0], t[1]) for t in taps) == _TAPS_3X3):
+        # 3x3 / stride 1 / 64 -> 64: all 576 columns in one workgroup, the input rows shared between the taps
+        tile = 18
+        splits = _num_cus()
+    elif tile >= 10:
         bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256), 13: (64, 256), 14: (256, 64), 15: (64, 256),
                   16: (256, 256), 17: (256, 256)}[tile]
         splits = _wgrad_splits(M, N, kc, 1, bn, bc, WGRAD_RING_TARGET_BLOCKS or _num_cus())
