@@ -1645,6 +1645,244 @@ static int launch_conv3x3_halo(const GatherGemmArgs& a, hipStream_t stream) {
     return pdt_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 7x7 / stride 2 stem on 4-element pixels (packed rows, see gather_gemm_kernel), input rows shared in LDS.
+//
+// In packed-row form a kernel row of an output pixel is 32 contiguous elements (64 bytes) of the zero-bordered input,
+// starting 16 bytes (one stride of two 4-element pixels) after its left neighbour's: the tap-table kernel fetches those
+// 64 bytes per pixel and kernel row - fourteen times the bytes the input holds - through the L2 -> LDS path, which is
+// what bounds it.  Here the input is streamed through LDS once, as it sits in memory: a circular 64 KB image of the
+// byte range a few tiles need (rows of all images are contiguous, so the window of a tile of 256 consecutive output
+// pixels is one contiguous range), and an A fragment is read straight out of it - lane (pixel, 16-byte chunk) reads
+// at row byte + 16 (ow + chunk), so the 16 pixels of a fragment read 16 consecutive chunks and no swizzle is needed.
+// The weights (64 x 7 x 32) stay in LDS at a row pitch of 464 bytes (a pitch of 448 would put four rows on a bank).
+//   tile of 256 output pixels, 8 waves x (32 pixels x 64 channels), 7 kernel rows x 8 MFMAs per wave
+//   every tile issues exactly three DMA requests per wave (real 1 KB pieces of the window two tiles ahead, or dummies
+//   into a trash area), so one counted wait per tile retires the previous tile's requests
+// ------------------------------------------------------------------------------------------------
+constexpr int ROWS_B_OFF = 65536;                    // weights: 64 rows of 464 bytes
+constexpr int ROWS_B_PITCH = 464;
+constexpr int ROWS_EPI_OFF = ROWS_B_OFF + 64 * ROWS_B_PITCH;  // 95232
+constexpr int ROWS_TRASH_OFF = ROWS_EPI_OFF + 8 * 2048;       // one KB per wave for the dummy requests
+constexpr int ROWS_LDS = ROWS_TRASH_OFF + 8 * 1024;
+constexpr int ROWS_LA = 2;    // the window of tile t + 2 is requested at the top of tile t and awaited at the end of tile t + 1
+constexpr int ROWS_REQ = 3;   // requests per wave and tile: 24 KB, more than the window moves per tile (<= 20 KB across an image boundary)
+
+__global__ __launch_bounds__(512) void conv_rows7_kernel(const GatherGemmArgs p, const int tiles_per_wg, const long long in_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
+    constexpr int T = 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int total_tiles = (p.M + 255) >> 8;
+    const int tile_begin = blockIdx.x * tiles_per_wg;
+    const int ntiles = min(tiles_per_wg, total_tiles - tile_begin);
+    const int m_begin = tile_begin << 8;
+    const uint32_t RB = static_cast<uint32_t>(p.Win) * p.cs * 2u;  // bytes per input row (a multiple of 16)
+
+    // byte offset (from the start of the input) of kernel row 0 of output pixel m, at its first pixel
+    auto row_byte = [&](int m, uint32_t& ow) -> long long {
+        const uint32_t mm = static_cast<uint32_t>(min(m, p.M - 1));
+        const uint32_t img = fastdiv(mm, p.div_ab);
+        const uint32_t rem = mm - img * (p.OA * p.OB);
+        const uint32_t oh = fastdiv(rem, p.div_b);
+        ow = rem - oh * p.OB;
+        return static_cast<long long>(img * p.Hin + oh * p.istr) * RB;
+    };
+    // window of tile t (clamped to the launch): [first byte of its first pixel's first kernel row, last byte of its last pixel's last)
+    uint32_t dummy;
+    const long long org = row_byte(m_begin, dummy) & ~1023ll;  // LDS position 0 holds input byte `org`
+    auto need_end = [&](int t) -> uint32_t {  // relative to org
+        const int last = min(m_begin + (min(t, ntiles - 1) << 8) + 255, p.M - 1);
+        return static_cast<uint32_t>(row_byte(last, dummy) + static_cast<long long>(T) * RB - org);
+    };
+    bf16* abase = const_cast<bf16*>(p.A) + org / 2;
+    // The window is requested in groups of 8 pieces (1 KB per wave).  Every call issues exactly ROWS_REQ requests per
+    // wave: the next groups that start below the end of tile t's window, and dummies into a trash area once the cursor
+    // has passed it - a fixed count per tile is what lets one counted wait retire "everything but this tile's requests".
+    uint32_t ld_off = 0;  // first byte (from org) of the next group
+    auto issue_tile = [&](int t) {
+        const uint32_t end = need_end(t);
+#pragma unroll
+        for (int k = 0; k < ROWS_REQ; ++k) {
+            const bool real = ld_off < end;  // (wave-uniform)
+            const uint32_t off = ld_off + 1024u * wave + 16u * lane;
+            const uint32_t voff = (real && org + off + 16 <= in_bytes) ? off : OUT_OF_RANGE;
+            char* dst = real ? smem + ((ld_off + 1024u * wave) & 0xffffu) : smem + ROWS_TRASH_OFF + wave * 1024;
+            buffer_load_lds_16(abase, (lds_void_t*)dst, voff, 0);
+            if (real) ld_off += 8192u;
+        }
+    };
+
+    // ---- weights -> LDS (plain loads: the LDS pitch differs from the memory pitch)
+    for (int c = tid; c < 64 * (T * 4); c += 512) {
+        const int n = c / (T * 4), q = c - n * (T * 4);
+        *reinterpret_cast<bf16x8*>(smem + ROWS_B_OFF + n * ROWS_B_PITCH + q * 16) =
+            *reinterpret_cast<const bf16x8*>(p.B + static_cast<size_t>(n) * p.ldb + q * 8);
+    }
+    // the windows of the first ROWS_LA tiles (at most 56 KB, see the launcher)
+    for (int rep = 0; rep < (7 + ROWS_REQ - 1) / ROWS_REQ; ++rep) issue_tile(ROWS_LA - 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const uint32_t b_off0 = ROWS_B_OFF + lr * ROWS_B_PITCH + lg * 16;
+    const int ech = lane & 7, erow = lane >> 3;
+    bf16* epi = reinterpret_cast<bf16*>(smem + ROWS_EPI_OFF + wave * 2048);
+    float s1[8], s2[8], f0f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = f0f[e] = 0.f;
+    float fcnt = 0.f;
+    bool f0_fresh = true;
+    const bool want_stats = p.stats != nullptr;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][4];
+
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int m0 = m_begin + (ti << 8);
+        issue_tile(ti + ROWS_LA);
+        uint32_t a_byte[2];  // LDS-relative byte of this lane's chunk of kernel row 0, per 16-pixel block (before the wrap)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t ow;
+            const long long rb = row_byte(m0 + 32 * wave + 16 * i + lr, ow);
+            a_byte[i] = static_cast<uint32_t>(rb - org) + 16u * (ow + lg);
+        }
+        bf16x8 fa[2][2], fb[2][4];
+        auto load = [&](const int kh, const int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(smem + ((a_byte[i] + kh * RB) & 0xffffu));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(smem + b_off0 + j * (16 * ROWS_B_PITCH) + kh * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma = [&](const int kh, const int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], kh == 0 ? zero4 : acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load(0, 0);
+#pragma unroll
+        for (int kh = 0; kh < T; ++kh) {
+            if (kh + 1 < T) load(kh + 1, (kh + 1) & 1);
+            mma(kh, kh & 1);
+        }
+        // the previous tile's requests have landed (this tile's may stay in flight); in front of the stores
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS_REQ) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue (see conv3x3_halo_kernel)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = j * 16 + lg * 4;
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f32_to_bf16(acc[i][j][e]);
+                *reinterpret_cast<bf16x4*>(epi + lr * 64 + ((((nl >> 3) ^ lr) & 7) << 3) + ((nl ^ (lr >> 1)) & 4)) = v;
+            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int row = ps * 8 + erow;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(epi + row * 64 + (((ech ^ row) & 7) << 3));
+                if (ps == 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+                if (i == 0 && ps == 0 && f0_fresh) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f0f[e] = bf16_to_f32(v[e]);
+                    f0_fresh = false;
+                }
+                const int m = m0 + 32 * wave + 16 * i + row;
+                if (m < p.M) {
+                    bf16* dst = p.Out + static_cast<size_t>(static_cast<uint32_t>(m)) * static_cast<uint32_t>(p.ldo) + ech * 8;
+                    if (p.out_nt) {
+                        asm volatile("" ::: "memory");
+                        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(dst));
+                        asm volatile("" ::: "memory");
+                    } else {
+                        *reinterpret_cast<bf16x8*>(dst) = v;
+                    }
+                    if (want_stats) {
+                        fcnt += 1.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = bf16_to_f32(v[e]) - f0f[e];
+                            s1[e] += f;
+                            s2[e] += f * f;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!want_stats) return;
+    const int ncol = ech * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float P = p.pivot != nullptr ? p.pivot[ncol + e] : 0.f;
+        const float dl = f0f[e] - P;
+        s2[e] += dl * (2.f * s1[e] + fcnt * dl);
+        s1[e] += fcnt * dl;
+        if (p.pivot != nullptr && lane < 8) p.stats[static_cast<size_t>(PDT_STAT_SLOTS) * 2 * 64 + ncol + e] = P;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s1[e] += __shfl_xor(s1[e], o, 64);
+            s2[e] += __shfl_xor(s2[e], o, 64);
+        }
+    }
+    if (lane < 8) {
+        float* slot = p.stats + static_cast<size_t>(blockIdx.x % PDT_STAT_SLOTS) * p.stat_rows * 64;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __hip_atomic_fetch_add(slot + ncol + e, s1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(slot + 64 + ncol + e, s2[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the packed-row launch (before its conversion into K-steps) is the form conv_rows7_kernel handles
+static bool conv_rows7_applies(const GatherGemmArgs& a, int smallc, int T) {
+    static const bool enabled = std::getenv("PDT_CONV_ROWS") == nullptr || std::atoi(std::getenv("PDT_CONV_ROWS")) != 0;  // (A/B switch)
+    if (!enabled || smallc != 32 || T != 7 || a.C != 4 || a.N != 64 || a.ldo != 64 || a.istr != 2 || a.ldb < 7 * 32) return false;
+    if (a.ostr != 1 || a.oph != 0 || a.opw != 0 || a.OA != a.Hout || a.OB != a.Wout) return false;
+    if (a.bias != nullptr || a.addend != nullptr || a.act != 0 || a.xf != nullptr || a.bn_y != nullptr || a.out_nt > 1) return false;
+    if ((a.Win * 4 * 2) % 16 != 0) return false;
+    // the kernel rows of an output pixel are inside the input: (OA - 1) * 2 + 7 <= Hin, and 64 bytes from pixel 2 (OB - 1) fit the row
+    if ((a.OA - 1) * 2 + 7 > a.Hin || ((a.OB - 1) * 2) * 4 + 32 > a.Win * 4) return false;
+    // window of three tiles + what a tile can move + one group of over-fetch must fit the 64 KB image (see the kernel)
+    const long long RB = static_cast<long long>(a.Win) * 8;
+    const long long steps3 = (3 * 256 - 1 + a.OB - 1) / a.OB;   // output-row steps inside three tiles
+    const long long rows = steps3 * 2 + (a.Hin - 2 * (a.OA - 1)) + 7;  // + the jump at an image boundary + the kernel rows
+    if (rows * RB + 1024 + 8192 > 65536) return false;
+    const long long steps1 = (256 - 1 + a.OB - 1) / a.OB;
+    if ((steps1 * 2 + (a.Hin - 2 * (a.OA - 1))) * RB > ROWS_REQ * 8192) return false;  // a tile's requests keep up with the window
+    return true;
+}
+
+static int launch_conv_rows7(const GatherGemmArgs& a, hipStream_t stream) {
+    const int total = pdt_cdiv(a.M, 256);
+    const int cus = pdt_num_cus();
+    const int per = pdt_cdiv(total, cus);
+    const int grid = pdt_cdiv(total, per);
+    const long long images = a.M / (static_cast<long long>(a.OA) * a.OB);
+    const long long in_bytes = (images * a.Hin + 1) * a.Win * 8;  // (+ the spare row the caller keeps behind the last image)
+    if ((static_cast<long long>(per) * 256 / a.OB + 8) * 2 * a.Win * 8 >= (1ll << 31)) return -1;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rows7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS);
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured = true;
+    }
+    hipLaunchKernelGGL(conv_rows7_kernel, dim3(grid), dim3(512), ROWS_LDS, stream, a, per, in_bytes);
+    return pdt_launch_status();
+}
+
 // Outputs of at least this many bytes are written with non-temporal stores by the ring kernels.  A negative value is a
 // measurement aid: the ring kernels then skip the output store altogether (what the epilogue's stores cost a launch).
 static long long g_out_nt_bytes = 64ll << 20;
@@ -1706,6 +1944,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         a.tap_woff[t] = tap_woff[t];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (smallc && tile >= 13 && conv_rows7_applies(a, smallc, T)) return launch_conv_rows7(a, s);
     if (smallc && tile >= 13 && zeros != nullptr) {
         // packed rows on the ring kernels: one "tap" per K-step of 64 / tw kernel rows, a single 64-wide channel block.
         // The last K-step may reach one image row past the kernel (zero weights there): the caller keeps one readable

@@ -106,6 +106,9 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
         test_conv_forward_backward(hip, 3, 64, 64, 3, 1, 1, 63)
         test_conv_forward_backward(hip, 64, 64, 64, 3, 1, 1, 56)
         test_conv_forward_backward(hip, 5, 64, 64, 3, 1, 1, 23)  # (one too narrow: the tap-table kernel)
+        # the ImageNet stem on the kernel that streams the input rows through LDS once: several tiles per workgroup, so
+        # the circular input window wraps, and image boundaries inside a workgroup's range
+        test_conv_forward_backward(hip, 40, 3, 64, 7, 2, 3, 224)
 
 
 @pytest.mark.parametrize("tile", [13, 16])
