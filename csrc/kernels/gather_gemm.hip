@@ -2867,6 +2867,177 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 7x7 / stride 2 stem on 4-element pixels (packed rows), input streamed through LDS once.
+//
+//   dW[n][kh * 32 + e] = sum over output pixels of dY[pixel][n] * in[(2 oh + kh) row][8 ow + e]
+// The reduction runs over output pixels in a padded numbering with 128 positions per output row (positions >= OB have a
+// zero dY row), so a K-step of 64 is half an output row: its seven input rows are wave-uniform, and lane (pixel r,
+// 4 elements) of a transposed fragment read addresses "row byte + 16 r + ..." - one scalar per kernel row plus a
+// per-lane constant.  The input sits in LDS as in conv_rows7_kernel (a circular 64 KB image of the byte range around
+// the K-step), with its first 2 KB mirrored behind the end so that a fragment never wraps.
+//   8 waves = 4 (16 output channels) x 2 (elements 0-15 / 16-31 of every kernel row): 7 accumulators, 14 MFMAs per K-step
+//   per K-step and wave 3 DMA requests: one 1 KB piece of the input window (or a dummy), its mirror / duplicate, and the
+//   dY rows three steps ahead - a fixed count, so "all but the last six" retires what the step reads.
+// The kernel is bound by reading dY (128 bytes per output pixel) from HBM.
+// ------------------------------------------------------------------------------------------------
+constexpr int WR_Y_OFF = 65536 + 2048;
+constexpr int WR_TRASH_OFF = WR_Y_OFF + 4 * 8192;
+constexpr int WR_LDS = WR_TRASH_OFF + 8 * 1024;
+constexpr int WR_LAX = 6;  // the input window is requested this many K-steps ahead (3 are needed; the rest absorbs image boundaries)
+
+__global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, const int total_steps, const int steps_per_wg,
+                                                          const long long in_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int split = blockIdx.x;
+    const int ks0 = split * steps_per_wg;
+    const int nsteps = min(steps_per_wg, total_steps - ks0);
+    const long long RB = static_cast<long long>(p.Win) * p.cp * 2;
+    // K-step s (launch-wide index) = half (s & 1) of output row line = s >> 1 = img * OA + oh; its first input row
+    auto in_row = [&](int s) -> long long {
+        const uint32_t line = static_cast<uint32_t>(min(s, total_steps - 1)) >> 1;
+        const uint32_t img = fastdiv(line, p.div_ab);
+        return static_cast<long long>(img) * p.Hin + static_cast<long long>(line - img * p.OA) * p.istr;
+    };
+    const long long org = (in_row(ks0) * RB) & ~1023ll;  // LDS position 0 holds input byte `org`
+    // (8 rows: the positions 112-127 of the last kernel row's fragment read on into the row behind it - times a zero dY row, but
+    // what they read must be data or zeros, never LDS that nothing has written)
+    auto need_end = [&](int s) -> uint32_t { return static_cast<uint32_t>((in_row(min(s, ks0 + nsteps - 1)) + 8) * RB - org); };
+    bf16* xbase = const_cast<bf16*>(p.X) + org / 2;
+    const long long m_base = static_cast<long long>(ks0 >> 1) * p.OB;
+    bf16* ybase = const_cast<bf16*>(p.dY) + m_base * p.ldy;
+
+    const int lrow = lane >> 3, pc = lane & 7;
+    uint32_t ld_off = 0;  // first byte (from org) of the next group of 8 pieces
+    auto issue_x = [&](int s) {  // two requests: the next piece of the window if step s needs it (else a dummy), and its mirror / duplicate
+        const bool real = ld_off < need_end(s);  // (wave-uniform)
+        const uint32_t off = ld_off + 1024u * wave;
+        const uint32_t pos = off & 0xffffu;
+        const uint32_t voff = (real && org + off + 16 * lane + 16 <= in_bytes) ? off + 16u * lane : OUT_OF_RANGE;
+        char* dst = real ? smem + pos : smem + WR_TRASH_OFF + wave * 1024;
+        buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
+        buffer_load_lds_16(xbase, (lds_void_t*)((real && pos < 2048u) ? dst + 65536 : dst), voff, 0);
+        if (real) ld_off += 8192u;
+    };
+    auto issue_y = [&](int ks) {  // dY rows of local K-step ks: positions 64 half + r of its output row (zeros beyond OB / the range)
+        const int s = ks0 + ks;
+        const int r = 8 * wave + lrow;
+        const int ow = 64 * (s & 1) + r;
+        const int chunk = (((pc >> 1) ^ ((r >> 1) & 3)) << 1) | (pc & 1);
+        const bool ok = ks < nsteps && ow < p.OB;
+        const long long m = static_cast<long long>(s >> 1) * p.OB + ow - m_base;
+        const uint32_t voff = ok ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
+        buffer_load_lds_16(ybase, (lds_void_t*)(smem + WR_Y_OFF + (ks & 3) * 8192 + wave * 1024), voff, 0);
+    };
+    for (int rep = 0; rep < 8; ++rep) issue_x(ks0 + WR_LAX);  // (at most 7 groups are real: the launcher checks the window's size)
+    issue_y(0); issue_y(1); issue_y(2);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    f32x4 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_void_t*)smem));
+    const int krow = 4 * g + q4;
+    const uint32_t y_off = lds0 + WR_Y_OFF + static_cast<uint32_t>(krow * 64 + ((wr ^ ((krow >> 1) & 3)) << 4) + 4 * pp) * 2u;
+    const uint32_t x_lane = lds0 + static_cast<uint32_t>(16 * krow + 32 * wc + 8 * pp);
+
+    for (int ks = 0; ks < nsteps; ++ks) {
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        issue_x(ks0 + ks + WR_LAX);
+        issue_y(ks + 3);
+        const int s = ks0 + ks;
+        const long long rb = in_row(s) * RB + 1024 * (s & 1) - org;  // first pixel of the K-step in kernel row 0
+        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 8192);
+        s16x4 ylo[2], yhi[2], xlo[7][2], xhi[7][2];
+        {
+            const uint32_t a = y_off + ys;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yhi[0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(ylo[1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yhi[1]) : "v"(a) : "memory");
+        }
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const uint32_t a = x_lane + (static_cast<uint32_t>(rb + kh * RB) & 0xffffu);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kh][0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(xhi[kh][0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(xlo[kh][1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:768" : "=v"(xhi[kh][1]) : "v"(a) : "memory");
+        }
+        auto mma = [&](const int lo_kh, const int hi_kh) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const s16x8 yv = {ylo[kk][0], ylo[kk][1], ylo[kk][2], ylo[kk][3], yhi[kk][0], yhi[kk][1], yhi[kk][2], yhi[kk][3]};
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) {
+                    if (kh < lo_kh || kh >= hi_kh) continue;
+                    const s16x8 xv = {xlo[kh][kk][0], xlo[kh][kk][1], xlo[kh][kk][2], xlo[kh][kk][3],
+                                      xhi[kh][kk][0], xhi[kh][kk][1], xhi[kh][kk][2], xhi[kh][kk][3]};
+                    acc[kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv), acc[kh], 0, 0, 0);
+                }
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // dY and kernel rows 0-2 (of 32 reads, the first 17) are back
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 3);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(3, 6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(6, 7);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // D[n][column]: lane holds output channels (lane >> 4) * 4 + e of its block, column lane & 15
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+        const int col = kh * 32 + 16 * wc + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = wr * 16 + (lane >> 4) * 4 + e;
+            __hip_atomic_fetch_add(p.dW + static_cast<size_t>(split) * p.split_stride + static_cast<size_t>(n) * p.ldw + col, acc[kh][e],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// tile 19: packed-row weight gradient of a 7-row kernel with 32-element rows on 4-element pixels, stride 2, 64 output channels
+static int launch_wgrad_rows7(WgradArgs a, int T, int splits, hipStream_t stream) {
+    // (a.C: elements per pixel, a.tw: row width on entry)
+    if (T != 7 || a.tw != 32 || a.cp != 4 || a.N != 64 || a.istr != 2 || a.OB > 128 || a.OB <= 64 || a.ldw < 7 * 32 || a.xf != nullptr ||
+        a.dbias != nullptr || (a.M % (a.OA * a.OB)) != 0 || (a.Win * 8) % 16 != 0)
+        return -1;
+    const long long RB = static_cast<long long>(a.Win) * 8;
+    if ((a.OA - 1) * 2 + 7 > a.Hin || 2096 > 2 * RB) return -1;  // (a fragment reaches 2096 bytes from the row's start: positions up to 127)
+    const long long jump = a.Hin - 2 * (a.OA - 1);  // input rows from an image's last output row to the next image's first
+    // window of a K-step (8 rows) + WR_LAX steps of lookahead + an image boundary + one group of over-fetch inside the
+    // 64 KB image; the prologue's 8 groups cover the first window
+    if ((8 + (WR_LAX / 2 + 1) * 2 + jump) * RB + 1024 + 8192 > 65536 || (8 + (WR_LAX / 2 + 1) * 2 + jump) * RB + 1024 > 8 * 8192) return -1;
+    if ((2 + jump) * RB > 3 * 8192) return -1;  // one group per K-step catches up with a boundary within the lookahead's slack
+    const long long images = a.M / (static_cast<long long>(a.OA) * a.OB);
+    const long long total = images * a.OA * 2;
+    if (total >= (1ll << 30)) return -1;
+    const int per = pdt_cdiv(total, splits);
+    const int grid = pdt_cdiv(total, per);
+    if ((static_cast<long long>(per) / 2 + 8) * (2 * RB > a.OB * a.ldy * 2ll ? 2 * RB : a.OB * a.ldy * 2ll) >= (1ll << 31)) return -1;
+    const long long in_bytes = (images * a.Hin + 1) * RB;  // (+ the spare row behind the last image)
+    a.div_ab = make_fastdiv(a.OA);
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rows7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS);
+        if (e != hipSuccess) return static_cast<int>(e);
+        configured = true;
+    }
+    hipLaunchKernelGGL(wgrad_rows7_kernel, dim3(grid), dim3(512), WR_LDS, stream, a, static_cast<int>(total), per, in_bytes);
+    return pdt_launch_status();
+}
+
 // tile 18: the launch must be the 3x3 / stride 1 / 64 -> 64 form; `splits` workgroups, one range of padded pixels each
 static int launch_wgrad3x3_halo(WgradArgs a, int splits, hipStream_t stream) {
     if (a.T != 9 || a.C != 64 || a.N != 64 || a.istr != 1 || a.OA != a.Hin || a.OB != a.Win || a.Win > 61 || a.Win < 1 || a.tw != 0 ||
@@ -2993,7 +3164,7 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     if (smallc) {
         // packed rows: `smallc` is the row width tw, C the elements per pixel on entry, T the number of kernel rows;
         // the kernel sees (kernel row, position in row) as its channel axis
-        if ((smallc != 32 && smallc != 64) || (C != 4 && C != 8) || (tile >= 10 && tile != 15)) return -1;
+        if ((smallc != 32 && smallc != 64) || (C != 4 && C != 8) || (tile >= 10 && tile != 15 && tile != 19)) return -1;
         a.cp = C;
         a.tw = smallc;
         if (ldw < T * smallc) return -1;
@@ -3028,6 +3199,9 @@ PDT_API int pdt_wgrad(const void* dY, const void* X, float* dW, int M, int N, in
     if (tile == 18) {
         if (smallc || wgrad_grouping) return -1;
         return launch_wgrad3x3_halo(a, splits, s);
+    } else if (tile == 19) {
+        if (!smallc || wgrad_grouping) return -1;
+        return launch_wgrad_rows7(a, T, splits, s);
     } else if (tile == 15) {
         return launch_wgrad_ring<64, 256, 2, 4, 3, 1>(a, gy, s);
     } else if (smallc) {

@@ -682,6 +682,11 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         # 3x3 / stride 1 / 64 -> 64: all 576 columns in one workgroup, the input rows shared between the taps
         tile = 18
         splits = _num_cus()
+    elif (WGRAD_HALO and tile == 15 and smallc == 32 and C == 4 and len(taps) == 7 and N == 64 and istr == 2 and 64 < OB <= 128
+          and dbias is None and xf is None and M >= 64 * _num_cus()):
+        # the ImageNet stem: the padded input streamed through LDS once, all seven kernel rows read from it
+        tile = 19
+        splits = _num_cus()
     elif tile >= 10:
         bn, bc = {10: (128, 128), 11: (256, 128), 12: (128, 256), 13: (64, 256), 14: (256, 64), 15: (64, 256),
                   16: (256, 256), 17: (256, 256)}[tile]
