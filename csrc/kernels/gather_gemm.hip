@@ -2872,19 +2872,19 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
 //
 //   dW[n][kh * 32 + e] = sum over output pixels of dY[pixel][n] * in[(2 oh + kh) row][8 ow + e]
 // The reduction runs over output pixels in a padded numbering with 128 positions per output row (positions >= OB have a
-// zero dY row), so a K-step of 64 is half an output row: its seven input rows are wave-uniform, and lane (pixel r,
+// zero dY row), and a K-step is one output row: its seven input rows are wave-uniform, and lane (pixel r,
 // 4 elements) of a transposed fragment read addresses "row byte + 16 r + ..." - one scalar per kernel row plus a
 // per-lane constant.  The input sits in LDS as in conv_rows7_kernel (a circular 64 KB image of the byte range around
-// the K-step), with its first 2 KB mirrored behind the end so that a fragment never wraps.
-//   8 waves = 4 (16 output channels) x 2 (elements 0-15 / 16-31 of every kernel row): 7 accumulators, 14 MFMAs per K-step
-//   per K-step and wave 3 DMA requests: one 1 KB piece of the input window (or a dummy), its mirror / duplicate, and the
-//   dY rows three steps ahead - a fixed count, so "all but the last six" retires what the step reads.
+// the K-step), with its first 3 KB mirrored behind the end so that a fragment never wraps.
+//   8 waves = 4 (16 output channels) x 2 (elements 0-15 / 16-31 of every kernel row): 7 accumulators, 28 MFMAs per K-step
+//   per K-step and wave 4 DMA requests: one 1 KB piece of the input window (or a dummy), its mirror / duplicate, and the
+//   dY rows three steps ahead (two pieces) - a fixed count, so "all but the last eight" retires what the step reads.
 // The kernel is bound by reading dY (128 bytes per output pixel) from HBM.
 // ------------------------------------------------------------------------------------------------
-constexpr int WR_Y_OFF = 65536 + 2048;
-constexpr int WR_TRASH_OFF = WR_Y_OFF + 4 * 8192;
+constexpr int WR_Y_OFF = 65536 + 3072;
+constexpr int WR_TRASH_OFF = WR_Y_OFF + 4 * 16384;
 constexpr int WR_LDS = WR_TRASH_OFF + 8 * 1024;
-constexpr int WR_LAX = 6;  // the input window is requested this many K-steps ahead (3 are needed; the rest absorbs image boundaries)
+constexpr int WR_LAX = 5;  // the input window is requested this many K-steps ahead (3 are needed; the rest absorbs image boundaries)
 
 __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, const int total_steps, const int steps_per_wg,
                                                           const long long in_bytes) {
@@ -2896,9 +2896,9 @@ __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, con
     const int ks0 = split * steps_per_wg;
     const int nsteps = min(steps_per_wg, total_steps - ks0);
     const long long RB = static_cast<long long>(p.Win) * p.cp * 2;
-    // K-step s (launch-wide index) = half (s & 1) of output row line = s >> 1 = img * OA + oh; its first input row
+    // K-step s (launch-wide index) = output row s = img * OA + oh (128 positions); its first input row
     auto in_row = [&](int s) -> long long {
-        const uint32_t line = static_cast<uint32_t>(min(s, total_steps - 1)) >> 1;
+        const uint32_t line = static_cast<uint32_t>(min(s, total_steps - 1));
         const uint32_t img = fastdiv(line, p.div_ab);
         return static_cast<long long>(img) * p.Hin + static_cast<long long>(line - img * p.OA) * p.istr;
     };
@@ -2907,7 +2907,7 @@ __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, con
     // what they read must be data or zeros, never LDS that nothing has written)
     auto need_end = [&](int s) -> uint32_t { return static_cast<uint32_t>((in_row(min(s, ks0 + nsteps - 1)) + 8) * RB - org); };
     bf16* xbase = const_cast<bf16*>(p.X) + org / 2;
-    const long long m_base = static_cast<long long>(ks0 >> 1) * p.OB;
+    const long long m_base = static_cast<long long>(ks0) * p.OB;
     bf16* ybase = const_cast<bf16*>(p.dY) + m_base * p.ldy;
 
     const int lrow = lane >> 3, pc = lane & 7;
@@ -2919,20 +2919,23 @@ __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, con
         const uint32_t voff = (real && org + off + 16 * lane + 16 <= in_bytes) ? off + 16u * lane : OUT_OF_RANGE;
         char* dst = real ? smem + pos : smem + WR_TRASH_OFF + wave * 1024;
         buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
-        buffer_load_lds_16(xbase, (lds_void_t*)((real && pos < 2048u) ? dst + 65536 : dst), voff, 0);
+        buffer_load_lds_16(xbase, (lds_void_t*)((real && pos < 3072u) ? dst + 65536 : dst), voff, 0);
         if (real) ld_off += 8192u;
     };
-    auto issue_y = [&](int ks) {  // dY rows of local K-step ks: positions 64 half + r of its output row (zeros beyond OB / the range)
+    auto issue_y = [&](int ks) {  // dY rows of local K-step ks: positions 0-127 of its output row (zeros beyond OB / the range), two requests
         const int s = ks0 + ks;
-        const int r = 8 * wave + lrow;
-        const int ow = 64 * (s & 1) + r;
-        const int chunk = (((pc >> 1) ^ ((r >> 1) & 3)) << 1) | (pc & 1);
-        const bool ok = ks < nsteps && ow < p.OB;
-        const long long m = static_cast<long long>(s >> 1) * p.OB + ow - m_base;
-        const uint32_t voff = ok ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
-        buffer_load_lds_16(ybase, (lds_void_t*)(smem + WR_Y_OFF + (ks & 3) * 8192 + wave * 1024), voff, 0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = 8 * wave + lrow;  // row inside the 64-row half (the swizzle's period divides 64)
+            const int ow = 64 * k + r;
+            const int chunk = (((pc >> 1) ^ ((r >> 1) & 3)) << 1) | (pc & 1);
+            const bool ok = ks < nsteps && ow < p.OB;
+            const long long m = static_cast<long long>(s) * p.OB + ow - m_base;
+            const uint32_t voff = ok ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
+            buffer_load_lds_16(ybase, (lds_void_t*)(smem + WR_Y_OFF + (ks & 3) * 16384 + k * 8192 + wave * 1024), voff, 0);
+        }
     };
-    for (int rep = 0; rep < 8; ++rep) issue_x(ks0 + WR_LAX);  // (at most 7 groups are real: the launcher checks the window's size)
+    for (int rep = 0; rep < 8; ++rep) issue_x(ks0 + WR_LAX);  // (at most 8 groups are real: the launcher checks the window's size)
     issue_y(0); issue_y(1); issue_y(2);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -2946,51 +2949,57 @@ __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, con
     const uint32_t x_lane = lds0 + static_cast<uint32_t>(16 * krow + 32 * wc + 8 * pp);
 
     for (int ks = 0; ks < nsteps; ++ks) {
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        // per K-step and wave: X, X', Y, Y' - the dY rows of this step were the last two requests of step ks - 3
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         issue_x(ks0 + ks + WR_LAX);
         issue_y(ks + 3);
-        const int s = ks0 + ks;
-        const long long rb = in_row(s) * RB + 1024 * (s & 1) - org;  // first pixel of the K-step in kernel row 0
-        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 8192);
-        s16x4 ylo[2], yhi[2], xlo[7][2], xhi[7][2];
+        const long long rb = in_row(ks0 + ks) * RB - org;  // position 0 of the output row in kernel row 0
+        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 16384);
+        s16x4 ylo[4], yhi[4], xlo[7][4], xhi[7][4];  // [..][32-position slice]
         {
             const uint32_t a = y_off + ys;
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[0]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yhi[0]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(ylo[1]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yhi[1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(ylo[2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(yhi[2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(ylo[3]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:14336" : "=v"(yhi[3]) : "v"(a) : "memory");
         }
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh) {
+        auto read_x = [&](const int kh) {
             const uint32_t a = x_lane + (static_cast<uint32_t>(rb + kh * RB) & 0xffffu);
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[kh][0]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(xhi[kh][0]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(xlo[kh][1]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:768" : "=v"(xhi[kh][1]) : "v"(a) : "memory");
-        }
-        auto mma = [&](const int lo_kh, const int hi_kh) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(xlo[kh][2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1280" : "=v"(xhi[kh][2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1536" : "=v"(xlo[kh][3]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1792" : "=v"(xhi[kh][3]) : "v"(a) : "memory");
+        };
+        auto mma = [&](const int kh) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 4; ++kk) {
                 const s16x8 yv = {ylo[kk][0], ylo[kk][1], ylo[kk][2], ylo[kk][3], yhi[kk][0], yhi[kk][1], yhi[kk][2], yhi[kk][3]};
-#pragma unroll
-                for (int kh = 0; kh < 7; ++kh) {
-                    if (kh < lo_kh || kh >= hi_kh) continue;
-                    const s16x8 xv = {xlo[kh][kk][0], xlo[kh][kk][1], xlo[kh][kk][2], xlo[kh][kk][3],
-                                      xhi[kh][kk][0], xhi[kh][kk][1], xhi[kh][kk][2], xhi[kh][kk][3]};
-                    acc[kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv), acc[kh], 0, 0, 0);
-                }
+                const s16x8 xv = {xlo[kh][kk][0], xlo[kh][kk][1], xlo[kh][kk][2], xlo[kh][kk][3],
+                                  xhi[kh][kk][0], xhi[kh][kk][1], xhi[kh][kk][2], xhi[kh][kk][3]};
+                acc[kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv), acc[kh], 0, 0, 0);
             }
         };
-        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // dY and kernel rows 0-2 (of 32 reads, the first 17) are back
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 3);
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(3, 6);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(6, 7);
-        __builtin_amdgcn_sched_barrier(0);
+        // reads are awaited in order, 8 per kernel row, two kernel rows behind the newest request (the counter holds 15)
+        read_x(0);
+        read_x(1);
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            if (kh + 2 < 7) read_x(kh + 2);
+            if (kh + 2 < 7) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");      // 16 requests are younger than kernel row kh's
+            else if (kh + 1 < 7) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(kh);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -3018,14 +3027,14 @@ static int launch_wgrad_rows7(WgradArgs a, int T, int splits, hipStream_t stream
     const long long jump = a.Hin - 2 * (a.OA - 1);  // input rows from an image's last output row to the next image's first
     // window of a K-step (8 rows) + WR_LAX steps of lookahead + an image boundary + one group of over-fetch inside the
     // 64 KB image; the prologue's 8 groups cover the first window
-    if ((8 + (WR_LAX / 2 + 1) * 2 + jump) * RB + 1024 + 8192 > 65536 || (8 + (WR_LAX / 2 + 1) * 2 + jump) * RB + 1024 > 8 * 8192) return -1;
-    if ((2 + jump) * RB > 3 * 8192) return -1;  // one group per K-step catches up with a boundary within the lookahead's slack
+    if ((8 + WR_LAX * 2 + jump) * RB + 1024 + 8192 > 65536) return -1;
+    if ((2 + jump) * RB > (WR_LAX - 3 + 1) * 8192) return -1;  // one group per K-step catches up with a boundary within the lookahead's slack
     const long long images = a.M / (static_cast<long long>(a.OA) * a.OB);
-    const long long total = images * a.OA * 2;
+    const long long total = images * a.OA;
     if (total >= (1ll << 30)) return -1;
     const int per = pdt_cdiv(total, splits);
     const int grid = pdt_cdiv(total, per);
-    if ((static_cast<long long>(per) / 2 + 8) * (2 * RB > a.OB * a.ldy * 2ll ? 2 * RB : a.OB * a.ldy * 2ll) >= (1ll << 31)) return -1;
+    if ((static_cast<long long>(per) + 8) * (2 * RB > a.OB * a.ldy * 2ll ? 2 * RB : a.OB * a.ldy * 2ll) >= (1ll << 31)) return -1;
     const long long in_bytes = (images * a.Hin + 1) * RB;  // (+ the spare row behind the last image)
     a.div_ab = make_fastdiv(a.OA);
     static bool configured = false;
