@@ -2706,11 +2706,11 @@ static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t strea
 //
 //   workgroup = one contiguous range of padded pixels (a split), all 64 x 576 columns: 8 waves as 2 (32 output
 //   channels) x 4 (9 column blocks of 16 = consecutive (tap, channel quarter) pairs), 72 accumulator registers
-//   LDS: X rows in a ring of eight 64-row blocks, dY in a ring of four 64-row stages
-//   per K-step of 64 pixels: one barrier, 3 DMA requests per wave (64 new X rows six blocks ahead, dY three steps ahead)
+//   LDS: X rows in a ring of eight 64-row blocks, dY in a ring of four 128-row stages
+//   per K-step of 128 pixels: one barrier, 6 DMA requests per wave (128 new X rows and the dY rows two steps ahead)
 // ------------------------------------------------------------------------------------------------
-constexpr int WH_X_BYTES = 640 * 128;  // X rows: a ring of eight 64-row blocks, blocks 0 and 1 mirrored behind block 7
-constexpr int WH_LDS = WH_X_BYTES + 4 * 8192;
+constexpr int WH_X_BYTES = 704 * 128;  // X rows: a ring of eight 64-row blocks, blocks 0-2 mirrored behind block 7
+constexpr int WH_LDS = WH_X_BYTES + 4 * 16384;
 
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, const int P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2719,8 +2719,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     const int wr = wave >> 2, wc = wave & 3;
     const int H = p.Hin, W = p.Win, Wp = W + 2, HpWp = (H + 2) * Wp, HW = H * W;
     const int split = blockIdx.x;
-    const int ps = split * p.m_per_split, pe = min(P, ps + p.m_per_split);  // (ps is a multiple of 64)
-    const int nsteps = (pe - ps + 63) >> 6;
+    const int ps = split * p.m_per_split, pe = min(P, ps + p.m_per_split);  // (ps is a multiple of 128)
+    const int nsteps = (pe - ps + 127) >> 7;
     const int blk0 = ps >> 6;
     // 32-bit byte offsets from the first pixel of the image the range starts in
     const int img_lo = max(ps - 64, 0) / HpWp;
@@ -2740,10 +2740,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
         return (static_cast<int>(img) - img_lo) * HW + static_cast<int>(hp - 1u) * W + static_cast<int>(wp - 1u);
     };
     // X block b = padded rows [ps + 64 (b - 1), ps + 64 b), at ring position (blk0 + b - 1) mod 8.  The window of a K-step
-    // is three consecutive blocks; so that it never wraps (which would put a wrap test into every fragment address), ring
-    // positions 0 and 1 exist a second time behind position 7.  Every block is requested twice - the second request
-    // goes to the mirror position if there is one and to the same place otherwise - so that a K-step always issues the
-    // same number of requests (the counted waits below rely on that).
+    // is four consecutive blocks; so that it never wraps (which would put a wrap test into every fragment address), ring
+    // positions 0-2 exist a second time behind position 7.  Every block is requested twice - the second request goes to
+    // the mirror position if there is one and to the same place otherwise - so that a K-step always issues the same
+    // number of requests (the counted waits below rely on that).
     auto issue_x = [&](int b) {
         const int pos = (blk0 + b - 1) & 7;
         const int q = ps + 64 * (b - 1) + 8 * wave + lrow;
@@ -2752,19 +2752,23 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
         const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * 64 + chunk * 8) * 2u : OUT_OF_RANGE;
         char* dst = smem + (64 * pos + 8 * wave) * 128;
         buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
-        buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 2 ? 512 * 128 : 0)), voff, 0);
+        buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 3 ? 512 * 128 : 0)), voff, 0);
     };
-    auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + 64 ks, + 64); rows beyond the split are zeros
-        const int q = ps + 64 * ks + 8 * wave + lrow;
-        const int chunk = (((pc >> 1) ^ ((q >> 1) & 3)) << 1) | (pc & 1);
-        const int m = q < pe ? pixel_of(q) : -1;
-        const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
-        buffer_load_lds_16(ybase, (lds_void_t*)(smem + WH_X_BYTES + (ks & 3) * 8192 + wave * 1024), voff, 0);
+    auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + 128 ks, + 128), two requests; rows beyond the split are zeros
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = ps + 128 * ks + 64 * k + 8 * wave + lrow;
+            const int chunk = (((pc >> 1) ^ ((q >> 1) & 3)) << 1) | (pc & 1);
+            const int m = q < pe ? pixel_of(q) : -1;
+            const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
+            buffer_load_lds_16(ybase, (lds_void_t*)(smem + WH_X_BYTES + (ks & 3) * 16384 + k * 8192 + wave * 1024), voff, 0);
+        }
     };
-    // K-step ks reads X blocks ks, ks + 1, ks + 2 and dY stage ks.  Issue order (fixed, so that the counted wait of a
-    // K-step - "all but the last six requests" - covers what it reads): X0 X1 X2 Y0 X3 Y1 X4 Y2 X5, then in K-step ks:
-    // X(ks + 6), Y(ks + 3)  (an X block is two requests).
-    issue_x(0); issue_x(1); issue_x(2); issue_y(0); issue_x(3); issue_y(1); issue_x(4); issue_y(2); issue_x(5);
+    // K-step ks reads X blocks 2 ks .. 2 ks + 3 and dY stage ks; both are requested two K-steps ahead: six requests per
+    // wave and K-step (two X blocks twice, two dY pieces), so "all but the last six" is what a K-step waits for.
+    issue_x(0); issue_x(1); issue_x(2); issue_x(3); issue_x(4); issue_x(5);
+    issue_y(0); issue_y(1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     f32x4 acc[2][9];
 #pragma unroll
@@ -2791,12 +2795,13 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     }
 
     for (int ks = 0; ks < nsteps; ++ks) {
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-        issue_x(ks + 6);
-        issue_y(ks + 3);
-        const uint32_t xs = static_cast<uint32_t>(((blk0 + ks - 1) & 7) * 8192);  // the window's first row (block ks)
-        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 8192);
-        s16x4 ylo[2][2], yhi[2][2], xlo[2][3][2], xhi[2][3][2];  // [slice][...]; X: [buffer][block in group][slice]
+        if (ks > 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        issue_x(2 * ks + 6);
+        issue_x(2 * ks + 7);
+        issue_y(ks + 2);
+        const uint32_t xs = static_cast<uint32_t>(((blk0 + 2 * ks - 1) & 7) * 8192);  // the window's first row (block 2 ks)
+        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 16384);
+        s16x4 ylo[4][2], yhi[4][2], xlo[3][4], xhi[3][4];  // dY: [32-pixel slice][channel block]; X: [buffer][slice]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t a = y_off[i] + ys;
@@ -2804,47 +2809,49 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yhi[0][i]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(ylo[1][i]) : "v"(a) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yhi[1][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(ylo[2][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(yhi[2][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(ylo[3][i]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:14336" : "=v"(yhi[3][i]) : "v"(a) : "memory");
         }
-        auto read_x = [&](const int gr, const int buf) {  // (constants after inlining)
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) {
-                const uint32_t a = x_off[gr * 3 + jj] + xs;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[buf][jj][0]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xhi[buf][jj][0]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(xlo[buf][jj][1]) : "v"(a) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(xhi[buf][jj][1]) : "v"(a) : "memory");
-            }
+        auto read_x = [&](const int j, const int buf) {  // (constants after inlining)
+            const uint32_t a = x_off[j] + xs;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[buf][0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xhi[buf][0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(xlo[buf][1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(xhi[buf][1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(xlo[buf][2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(xhi[buf][2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(xlo[buf][3]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:14336" : "=v"(xhi[buf][3]) : "v"(a) : "memory");
         };
-        auto mma = [&](const int gr, const int buf) {
+        auto mma = [&](const int j, const int buf) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 4; ++kk) {
+                const s16x8 xv = {xlo[buf][kk][0], xlo[buf][kk][1], xlo[buf][kk][2], xlo[buf][kk][3],
+                                  xhi[buf][kk][0], xhi[buf][kk][1], xhi[buf][kk][2], xhi[buf][kk][3]};
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const s16x8 yv = {ylo[kk][i][0], ylo[kk][i][1], ylo[kk][i][2], ylo[kk][i][3],
                                       yhi[kk][i][0], yhi[kk][i][1], yhi[kk][i][2], yhi[kk][i][3]};
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) {
-                        const s16x8 xv = {xlo[buf][jj][kk][0], xlo[buf][jj][kk][1], xlo[buf][jj][kk][2], xlo[buf][jj][kk][3],
-                                          xhi[buf][jj][kk][0], xhi[buf][jj][kk][1], xhi[buf][jj][kk][2], xhi[buf][jj][kk][3]};
-                        acc[i][gr * 3 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
-                                                                                     acc[i][gr * 3 + jj], 0, 0, 0);
-                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv), acc[i][j], 0, 0, 0);
                 }
+            }
         };
+        // fragment reads return in order, 8 per column block; a block is requested two blocks ahead of its MFMAs (the
+        // counter holds 15: waiting for "at most 15 outstanding" is one read stricter than needed)
         read_x(0, 0);
         read_x(1, 1);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");  // the dY fragments and the first group are back
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_x(2, 0);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(2, 0);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j + 2 < 9) read_x(j + 2, (j + 2) % 3);
+            if (j + 2 < 9) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+            else if (j + 1 < 9) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(j, j % 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing requests
 
@@ -3063,7 +3070,7 @@ static int launch_wgrad3x3_halo(WgradArgs a, int splits, hipStream_t stream) {
     const long long P = static_cast<long long>(a.M / (a.Hin * a.Win)) * HpWp;
     if (P >= (1ll << 31) - 1024) return -1;
     int kps = pdt_cdiv(P, splits);
-    kps = pdt_cdiv(kps, 64) * 64;
+    kps = pdt_cdiv(kps, 128) * 128;
     const int grid = pdt_cdiv(P, kps);
     if ((static_cast<long long>(kps) + 2ll * HpWp + 1024) * (a.ldy > 64 ? a.ldy : 64) * 2 >= (1ll << 31)) return -1;
     a.m_per_split = kps;
