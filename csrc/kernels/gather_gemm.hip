@@ -2709,26 +2709,47 @@ static int launch_wgrad_ring_plain(const WgradArgs& a, int gy, hipStream_t strea
 //   LDS: X rows in a ring of eight 64-row blocks, dY in a ring of four 128-row stages
 //   per K-step of 128 pixels: one barrier, 6 DMA requests per wave (128 new X rows and the dY rows two steps ahead)
 // ------------------------------------------------------------------------------------------------
-constexpr int WH_X_BYTES = 704 * 128;  // X rows: a ring of eight 64-row blocks, blocks 0-2 mirrored behind block 7
-constexpr int WH_LDS = WH_X_BYTES + 4 * 16384;
+// C = 64: blocks of 64 rows, a K-step of 128 pixels, one workgroup for all 64 output channels.
+// C = 128 (and 128 output channels): rows of 256 bytes, blocks of 32 rows (W + 3 <= 32), a K-step of 64 pixels, and two
+// workgroups per pixel range (blockIdx.y), each with 64 of the output channels - 64 x 1152 columns are 144 accumulator
+// registers per lane.
+template <int C>
+struct WgradHalo {
+    static constexpr int BR = C == 64 ? 64 : 32;        // rows per block; a block is 8 KB
+    static constexpr int KS = 2 * BR;                   // pixels per K-step
+    static constexpr int KK = KS / 32;                  // 32-pixel slices per K-step
+    static constexpr int RB = 2 * C;                    // bytes per X row
+    static constexpr int UNITS = C / 16;                // 16-channel units per tap
+    static constexpr int NJ = 9 * UNITS / 4;            // column blocks per wave
+    static constexpr int GJ = 8 / (2 * KK);             // column blocks per group of 8 fragment reads
+    static constexpr int NG = NJ / GJ;                  // groups per K-step (9)
+    static constexpr int YP = KS / 64;                  // dY pieces (64 rows of 128 bytes) per K-step
+    static constexpr int X_BYTES = 11 * 8192;           // ring of eight blocks, blocks 0-2 mirrored behind block 7
+    static constexpr int Y_STAGE = KS * 128;
+    static constexpr int LDS = X_BYTES + 4 * Y_STAGE;
+    static constexpr int REQ = 4 + YP;                  // DMA requests per wave and K-step
+};
 
+template <int C>
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, const int P) {
+    using G = WgradHalo<C>;
+    constexpr int BR = G::BR, KS = G::KS, KK = G::KK, RB = G::RB, NJ = G::NJ, GJ = G::GJ, NG = G::NG;
+    static_assert(NG == 9 && NJ % GJ == 0, "nine groups of eight reads per K-step");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int H = p.Hin, W = p.Win, Wp = W + 2, HpWp = (H + 2) * Wp, HW = H * W;
     const int split = blockIdx.x;
-    const int ps = split * p.m_per_split, pe = min(P, ps + p.m_per_split);  // (ps is a multiple of 128)
-    const int nsteps = (pe - ps + 127) >> 7;
-    const int blk0 = ps >> 6;
+    const int nh = blockIdx.y;  // which 64 output channels
+    const int ps = split * p.m_per_split, pe = min(P, ps + p.m_per_split);  // (ps is a multiple of KS)
+    const int nsteps = (pe - ps + KS - 1) / KS;
+    const int blk0 = ps / BR;
     // 32-bit byte offsets from the first pixel of the image the range starts in
-    const int img_lo = max(ps - 64, 0) / HpWp;
-    bf16* xbase = const_cast<bf16*>(p.X) + static_cast<size_t>(img_lo) * HW * 64;
-    bf16* ybase = const_cast<bf16*>(p.dY) + static_cast<size_t>(img_lo) * HW * p.ldy;
+    const int img_lo = max(ps - BR, 0) / HpWp;
+    bf16* xbase = const_cast<bf16*>(p.X) + static_cast<size_t>(img_lo) * HW * C;
+    bf16* ybase = const_cast<bf16*>(p.dY) + static_cast<size_t>(img_lo) * HW * p.ldy + nh * 64;
 
-    // ---- loader: 1 KB pieces of 8 rows; lane -> (row, physical chunk); 32-byte units are XOR-ed with (row >> 1) & 3
-    const int lrow = lane >> 3, pc = lane & 7;
     // element offset of padded pixel q from the base pixel, or -1 for a border position / a pixel outside the tensor
     auto pixel_of = [&](int q) -> int {
         if (q < 0 || q >= P) return -1;
@@ -2739,42 +2760,48 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
         if (hp - 1u >= static_cast<uint32_t>(H) || wp - 1u >= static_cast<uint32_t>(W)) return -1;
         return (static_cast<int>(img) - img_lo) * HW + static_cast<int>(hp - 1u) * W + static_cast<int>(wp - 1u);
     };
-    // X block b = padded rows [ps + 64 (b - 1), ps + 64 b), at ring position (blk0 + b - 1) mod 8.  The window of a K-step
+    // ---- loader: 1 KB pieces; lane -> (row, physical 16-byte chunk); the 32-byte units of a row are XOR-ed with
+    // (row >> 1) & 3 (128-byte rows) or row & 7 (256-byte rows), see wgrad_ring_body
+    // X block b = padded rows [ps + BR (b - 1), ps + BR b), at ring position (blk0 + b - 1) mod 8.  The window of a K-step
     // is four consecutive blocks; so that it never wraps (which would put a wrap test into every fragment address), ring
     // positions 0-2 exist a second time behind position 7.  Every block is requested twice - the second request goes to
     // the mirror position if there is one and to the same place otherwise - so that a K-step always issues the same
     // number of requests (the counted waits below rely on that).
     auto issue_x = [&](int b) {
+        constexpr int CPR = RB / 16, RPP = 1024 / RB;  // chunks per row, rows per piece
+        const int lrow = lane / CPR, pc = lane % CPR;
         const int pos = (blk0 + b - 1) & 7;
-        const int q = ps + 64 * (b - 1) + 8 * wave + lrow;
-        const int chunk = (((pc >> 1) ^ ((q >> 1) & 3)) << 1) | (pc & 1);
+        const int q = ps + BR * (b - 1) + RPP * wave + lrow;
+        const int sw = C == 64 ? ((q >> 1) & 3) : (q & 7);
+        const int chunk = (((pc >> 1) ^ sw) << 1) | (pc & 1);
         const int m = pixel_of(q);
-        const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * 64 + chunk * 8) * 2u : OUT_OF_RANGE;
-        char* dst = smem + (64 * pos + 8 * wave) * 128;
+        const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * C + chunk * 8) * 2u : OUT_OF_RANGE;
+        char* dst = smem + pos * 8192 + wave * 1024;
         buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
-        buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 3 ? 512 * 128 : 0)), voff, 0);
+        buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 3 ? 8 * 8192 : 0)), voff, 0);
     };
-    auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + 128 ks, + 128), two requests; rows beyond the split are zeros
+    auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + KS ks, + KS), 64 of the channels; rows beyond the split are zeros
+        const int lrow = lane >> 3, pc = lane & 7;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = ps + 128 * ks + 64 * k + 8 * wave + lrow;
+        for (int k = 0; k < G::YP; ++k) {
+            const int q = ps + KS * ks + 64 * k + 8 * wave + lrow;
             const int chunk = (((pc >> 1) ^ ((q >> 1) & 3)) << 1) | (pc & 1);
             const int m = q < pe ? pixel_of(q) : -1;
             const uint32_t voff = m >= 0 ? static_cast<uint32_t>(m * p.ldy + chunk * 8) * 2u : OUT_OF_RANGE;
-            buffer_load_lds_16(ybase, (lds_void_t*)(smem + WH_X_BYTES + (ks & 3) * 16384 + k * 8192 + wave * 1024), voff, 0);
+            buffer_load_lds_16(ybase, (lds_void_t*)(smem + G::X_BYTES + (ks & 3) * G::Y_STAGE + k * 8192 + wave * 1024), voff, 0);
         }
     };
-    // K-step ks reads X blocks 2 ks .. 2 ks + 3 and dY stage ks; both are requested two K-steps ahead: six requests per
-    // wave and K-step (two X blocks twice, two dY pieces), so "all but the last six" is what a K-step waits for.
+    // K-step ks reads X blocks 2 ks .. 2 ks + 3 and dY stage ks; both are requested two K-steps ahead: REQ requests per
+    // wave and K-step (two X blocks twice, the dY pieces), so "all but the last REQ" is what a K-step waits for.
     issue_x(0); issue_x(1); issue_x(2); issue_x(3); issue_x(4); issue_x(5);
     issue_y(0); issue_y(1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    f32x4 acc[2][9];
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- transposed fragment reads (see wgrad_ring_body): lane (16 g + 4 q4 + pp) reads 4 columns of row 4 g + q4
     const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
@@ -2782,74 +2809,76 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     const int krow = 4 * g + q4;  // row inside a 32-pixel slice (+ 16 for the second read of a fragment)
     uint32_t y_off[2];  // dY fragments of this wave's two blocks of 16 output channels, slice 0 of stage 0
 #pragma unroll
-    for (int i = 0; i < 2; ++i) y_off[i] = lds0 + WH_X_BYTES + static_cast<uint32_t>(krow * 64 + (((2 * wr + i) ^ ((krow >> 1) & 3)) << 4) + 4 * pp) * 2u;
-    // This wave's column blocks: block 9 wc + j = (tap (9 wc + j) / 4, channels 16 ((9 wc + j) % 4) ..).  The fragment
-    // of tap (dh, dw) is the fragment of the rows shifted by dh (W + 2) + dw; a K-step starts at a multiple of 64 rows, so
-    // a lane's offset from the window's first row - swizzle included - is the same in every K-step.
-    uint32_t x_off[9];
+    for (int i = 0; i < 2; ++i) y_off[i] = lds0 + G::X_BYTES + static_cast<uint32_t>(krow * 64 + (((2 * wr + i) ^ ((krow >> 1) & 3)) << 4) + 4 * pp) * 2u;
+    // This wave's column blocks: block NJ wc + j = (tap, 16-channel unit).  The fragment of tap (dh, dw) is the fragment
+    // of the rows shifted by dh (W + 2) + dw; a K-step starts at a multiple of 64 rows, so a lane's offset from the window's
+    // first row - swizzle included - is the same in every K-step.
+    uint32_t x_off[NJ];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int cb = 9 * wc + j, tap = cb >> 2;
-        const int r = krow + (tap / 3 - 1) * Wp + (tap % 3 - 1);  // relative to the K-step's first pixel; >= -59
-        x_off[j] = lds0 + static_cast<uint32_t>((64 + r) * 128 + (((cb & 3) ^ ((r >> 1) & 3)) << 5) + 8 * pp);
+    for (int j = 0; j < NJ; ++j) {
+        const int cb = NJ * wc + j, tap = cb / G::UNITS, u = cb % G::UNITS;
+        const int r = krow + (tap / 3 - 1) * Wp + (tap % 3 - 1);  // relative to the K-step's first pixel; > -BR
+        const int sw = C == 64 ? ((r >> 1) & 3) : (r & 7);
+        x_off[j] = lds0 + static_cast<uint32_t>((BR + r) * RB + ((u ^ sw) << 5) + 8 * pp);
     }
 
     for (int ks = 0; ks < nsteps; ++ks) {
-        if (ks > 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        if (ks > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G::REQ) : "memory");
         issue_x(2 * ks + 6);
         issue_x(2 * ks + 7);
         issue_y(ks + 2);
         const uint32_t xs = static_cast<uint32_t>(((blk0 + 2 * ks - 1) & 7) * 8192);  // the window's first row (block 2 ks)
-        const uint32_t ys = static_cast<uint32_t>((ks & 3) * 16384);
-        s16x4 ylo[4][2], yhi[4][2], xlo[3][4], xhi[3][4];  // dY: [32-pixel slice][channel block]; X: [buffer][slice]
+        const uint32_t ys = static_cast<uint32_t>((ks & 3) * G::Y_STAGE);
+        s16x4 ylo[KK][2], yhi[KK][2], xlo[3][GJ][KK], xhi[3][GJ][KK];  // dY: [slice][channel block]; X: [buffer][block in group][slice]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t a = y_off[i] + ys;
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[0][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yhi[0][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(ylo[1][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yhi[1][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(ylo[2][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(yhi[2][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(ylo[3][i]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:14336" : "=v"(yhi[3][i]) : "v"(a) : "memory");
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ylo[kk][i]) : "v"(a), "n"(kk * 4096) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yhi[kk][i]) : "v"(a), "n"(kk * 4096 + 2048) : "memory");
+            }
         }
-        auto read_x = [&](const int j, const int buf) {  // (constants after inlining)
-            const uint32_t a = x_off[j] + xs;
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[buf][0]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xhi[buf][0]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(xlo[buf][1]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(xhi[buf][1]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(xlo[buf][2]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(xhi[buf][2]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(xlo[buf][3]) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:14336" : "=v"(xhi[buf][3]) : "v"(a) : "memory");
-        };
-        auto mma = [&](const int j, const int buf) {
+        auto read_x = [&](const int gr, const int buf) {  // (constants after inlining): 8 reads
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const s16x8 xv = {xlo[buf][kk][0], xlo[buf][kk][1], xlo[buf][kk][2], xlo[buf][kk][3],
-                                  xhi[buf][kk][0], xhi[buf][kk][1], xhi[buf][kk][2], xhi[buf][kk][3]};
+            for (int jj = 0; jj < GJ; ++jj) {
+                const uint32_t a = x_off[gr * GJ + jj] + xs;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const s16x8 yv = {ylo[kk][i][0], ylo[kk][i][1], ylo[kk][i][2], ylo[kk][i][3],
-                                      yhi[kk][i][0], yhi[kk][i][1], yhi[kk][i][2], yhi[kk][i][3]};
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv), acc[i][j], 0, 0, 0);
+                for (int kk = 0; kk < KK; ++kk) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xlo[buf][jj][kk]) : "v"(a), "n"(kk * 32 * RB) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[buf][jj][kk]) : "v"(a), "n"(kk * 32 * RB + 16 * RB) : "memory");
                 }
             }
         };
-        // fragment reads return in order, 8 per column block; a block is requested two blocks ahead of its MFMAs (the
-        // counter holds 15: waiting for "at most 15 outstanding" is one read stricter than needed)
+        auto mma = [&](const int gr, const int buf) {
+#pragma unroll
+            for (int jj = 0; jj < GJ; ++jj)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const s16x8 xv = {xlo[buf][jj][kk][0], xlo[buf][jj][kk][1], xlo[buf][jj][kk][2], xlo[buf][jj][kk][3],
+                                      xhi[buf][jj][kk][0], xhi[buf][jj][kk][1], xhi[buf][jj][kk][2], xhi[buf][jj][kk][3]};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const s16x8 yv = {ylo[kk][i][0], ylo[kk][i][1], ylo[kk][i][2], ylo[kk][i][3],
+                                          yhi[kk][i][0], yhi[kk][i][1], yhi[kk][i][2], yhi[kk][i][3]};
+                        acc[i][gr * GJ + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yv), __builtin_bit_cast(bf16x8, xv),
+                                                                                      acc[i][gr * GJ + jj], 0, 0, 0);
+                    }
+                }
+        };
+        // fragment reads return in order, 8 per group; a group is requested two groups ahead of its MFMAs (the counter
+        // holds 15: waiting for "at most 15 outstanding" is one read stricter than needed).  The dY fragments (4 KK
+        // reads) are in front of everything.
         read_x(0, 0);
         read_x(1, 1);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            if (j + 2 < 9) read_x(j + 2, (j + 2) % 3);
-            if (j + 2 < 9) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
-            else if (j + 1 < 9) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        for (int gr = 0; gr < NG; ++gr) {
+            if (gr + 2 < NG) read_x(gr + 2, (gr + 2) % 3);
+            if (gr + 2 < NG) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+            else if (gr + 1 < NG) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            mma(j, j % 3);
+            mma(gr, gr % 3);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -2857,17 +2886,17 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
 
     // D[n][column]: lane holds output channels (lane >> 4) * 4 + e of its block, column lane & 15
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int cb = 9 * wc + j, tap = cb >> 2;
+    for (int j = 0; j < NJ; ++j) {
+        const int cb = NJ * wc + j, tap = cb / G::UNITS;
         int woff = 0;
         for (int t = 0; t < 9; ++t)
             if (p.tap_dh[t] == tap / 3 - 1 && p.tap_dw[t] == tap % 3 - 1) woff = p.tap_woff[t];
-        const int col = woff + (cb & 3) * 16 + (lane & 15);
+        const int col = woff + (cb % G::UNITS) * 16 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int n = (2 * wr + i) * 16 + (lane >> 4) * 4 + e;
+                const int n = nh * 64 + (2 * wr + i) * 16 + (lane >> 4) * 4 + e;
                 __hip_atomic_fetch_add(p.dW + static_cast<size_t>(split) * p.split_stride + static_cast<size_t>(n) * p.ldw + col, acc[i][j][e],
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -3054,36 +3083,45 @@ static int launch_wgrad_rows7(WgradArgs a, int T, int splits, hipStream_t stream
     return pdt_launch_status();
 }
 
-// tile 18: the launch must be the 3x3 / stride 1 / 64 -> 64 form; `splits` workgroups, one range of padded pixels each
-static int launch_wgrad3x3_halo(WgradArgs a, int splits, hipStream_t stream) {
-    if (a.T != 9 || a.C != 64 || a.N != 64 || a.istr != 1 || a.OA != a.Hin || a.OB != a.Win || a.Win > 61 || a.Win < 1 || a.tw != 0 ||
-        a.xf != nullptr || a.dbias != nullptr || (a.M % (a.Hin * a.Win)) != 0)
-        return -1;
-    unsigned seen = 0;
-    for (int t = 0; t < 9; ++t) {
-        const int dh = a.tap_dh[t], dw = a.tap_dw[t];
-        if (dh < -1 || dh > 1 || dw < -1 || dw > 1 || a.tap_woff[t] < 0 || a.tap_woff[t] + 64 > a.ldw) return -1;
-        seen |= 1u << ((dh + 1) * 3 + dw + 1);
-    }
-    if (seen != 0x1ffu) return -1;
+// tile 18: the launch must be the 3x3 / stride 1 form with 64 -> 64 or 128 -> 128 channels; `splits` pixel ranges
+template <int C>
+static int launch_wgrad3x3_halo_c(WgradArgs a, int splits, hipStream_t stream) {
+    using G = WgradHalo<C>;
     const int Wp = a.Win + 2, HpWp = (a.Hin + 2) * Wp;
     const long long P = static_cast<long long>(a.M / (a.Hin * a.Win)) * HpWp;
     if (P >= (1ll << 31) - 1024) return -1;
     int kps = pdt_cdiv(P, splits);
-    kps = pdt_cdiv(kps, 128) * 128;
+    kps = pdt_cdiv(kps, G::KS) * G::KS;
     const int grid = pdt_cdiv(P, kps);
-    if ((static_cast<long long>(kps) + 2ll * HpWp + 1024) * (a.ldy > 64 ? a.ldy : 64) * 2 >= (1ll << 31)) return -1;
+    if ((static_cast<long long>(kps) + 2ll * HpWp + 1024) * (a.ldy > C ? a.ldy : C) * 2 >= (1ll << 31)) return -1;
     a.m_per_split = kps;
     a.div_ab = make_fastdiv(HpWp);
     a.div_b = make_fastdiv(Wp);
+    auto kernel = wgrad3x3_halo_kernel<C>;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) return static_cast<int>(e);
         configured = true;
     }
-    hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3(grid), dim3(512), WH_LDS, stream, a, static_cast<int>(P));
+    hipLaunchKernelGGL(kernel, dim3(grid, C / 64), dim3(512), G::LDS, stream, a, static_cast<int>(P));
     return pdt_launch_status();
+}
+
+static int launch_wgrad3x3_halo(const WgradArgs& a, int splits, hipStream_t stream) {
+    if (a.T != 9 || (a.C != 64 && a.C != 128) || a.N != a.C || a.istr != 1 || a.OA != a.Hin || a.OB != a.Win || a.Win < 1 || a.tw != 0 ||
+        a.xf != nullptr || a.dbias != nullptr || (a.M % (a.Hin * a.Win)) != 0)
+        return -1;
+    if (a.Win + 3 > WgradHalo<64>::BR && a.C == 64) return -1;   // the halo W + 3 fits one block
+    if (a.Win + 3 > WgradHalo<128>::BR && a.C == 128) return -1;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int dh = a.tap_dh[t], dw = a.tap_dw[t];
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1 || a.tap_woff[t] < 0 || a.tap_woff[t] + a.C > a.ldw) return -1;
+        seen |= 1u << ((dh + 1) * 3 + dw + 1);
+    }
+    if (seen != 0x1ffu) return -1;
+    return a.C == 64 ? launch_wgrad3x3_halo_c<64>(a, splits, stream) : launch_wgrad3x3_halo_c<128>(a, splits, stream);
 }
 
 static bool wgrad_is_plain(const WgradArgs& a) {

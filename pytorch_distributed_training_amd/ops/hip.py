@@ -606,8 +606,8 @@ WGRAD_RING_TARGET_BLOCKS = int(_os.environ.get("PDT_WGRAD_RING_TARGET_BLOCKS", "
 # Single-tap 256x256 weight gradients run on the ping-pong schedule (tile 17: the two wave rows of a workgroup alternate
 # between MFMA and LDS / DMA phases, as in the forward GEMM); 0 switches it off.
 WGRAD_PP = int(_os.environ.get("PDT_WGRAD_PP", "1"))
-# 3x3 / stride 1 / 64 -> 64 weight gradients on the kernel that shares the input rows between the taps (tile 18); 0: the
-# tap-table ring kernel
+# 3x3 / stride 1 / 64 -> 64 and 128 -> 128 weight gradients (and the stem's) on the kernels that share the input rows
+# between the taps (tiles 18, 19); 0: the tap-table ring kernels
 WGRAD_HALO = int(_os.environ.get("PDT_WGRAD_HALO", "1"))
 _TAPS_3X3 = sorted((i, j) for i in (-1, 0, 1) for j in (-1, 0, 1))
 
@@ -676,12 +676,13 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
         tile = 14  # 256 x 64
     if tile == 16 and WGRAD_PP and len(taps) == 1 and xf is None:
         tile = 17  # (the launcher falls back to 16 when the tap is not the identity mapping)
-    if (WGRAD_HALO and tile == 13 and not smallc and len(taps) == 9 and C == 64 and N == 64 and istr == 1 and OA == Hin
-            and OB == Win and Win <= 61 and xf is None and dbias is None and M >= 64 * _num_cus()
+    if (WGRAD_HALO and tile >= 10 and not smallc and len(taps) == 9 and C in (64, 128) and N == C and istr == 1 and OA == Hin
+            and OB == Win and Win <= (61 if C == 64 else 29) and xf is None and dbias is None and M >= 64 * _num_cus()
             and sorted((t[0], t[1]) for t in taps) == _TAPS_3X3):
-        # 3x3 / stride 1 / 64 -> 64: all 576 columns in one workgroup, the input rows shared between the taps
+        # 3x3 / stride 1 / 64 -> 64 (128 -> 128): all columns of 64 output channels in one workgroup, the input rows shared
+        # between the taps
         tile = 18
-        splits = _num_cus()
+        splits = _num_cus() * 64 // C
     elif (WGRAD_HALO and tile == 15 and smallc == 32 and C == 4 and len(taps) == 7 and N == 64 and istr == 2 and 64 < OB <= 128
           and dbias is None and xf is None and M >= 64 * _num_cus()):
         # the ImageNet stem: the padded input streamed through LDS once, all seven kernel rows read from it

@@ -111,6 +111,14 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
         test_conv_forward_backward(hip, 40, 3, 64, 7, 2, 3, 224)
 
 
+@pytest.mark.parametrize("nb,hw", [(24, 28), (40, 17), (23, 29)])
+def test_wgrad_of_the_128_channel_3x3_layers_with_shared_input_rows(hip, monkeypatch, nb, hw):
+    """128 -> 128 channels, 3x3, stride 1: the weight-gradient kernel that reduces over padded pixel indices and serves all
+    nine taps from one copy of the input rows (two workgroups per pixel range, 64 output channels each)."""
+    monkeypatch.setattr(hip, "WGRAD_HALO", 1)
+    test_conv_forward_backward(hip, nb, 128, 128, 3, 1, 1, hw)
+
+
 @pytest.mark.parametrize("tile", [13, 16])
 def test_linear_ring_variant_with_bias(hip, monkeypatch, tile):
     monkeypatch.setattr(hip, "_TILE_WIDE", tile)
