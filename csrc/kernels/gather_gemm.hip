@@ -1328,8 +1328,14 @@ static_assert(HALO_LDS <= 160 * 1024, "the halo kernel's buffers fit the LDS of 
 
 // EPI 0: forward statistics of the stored values (if p.stats);  EPI 4: BatchNorm-backward sums with the ReLU mask
 // recomputed from bn_y (see gather_gemm_ring_kernel)
-template <int EPI>
+// XF (EPI 0): the input is relu(A * scale[c] + shift[c]) - the BatchNorm + ReLU of the layer before, applied to its raw
+// output on the way in.  Every lane rewrites the 16-byte chunks its own DMA requests fetched, right after the counted
+// wait that retires them and in front of the barrier that publishes them: each input element is transformed once per
+// workgroup (in the tap-table kernels it would be once per tap), rows outside the tensor stay zero, and a tap outside
+// the image still reads the chunk of zeros.
+template <int EPI, bool XF = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs p, const int tiles_per_wg) {
+    static_assert(!XF || EPI == 0, "operand transform: forward launches");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr uint32_t OUT_OF_RANGE = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1356,31 +1362,55 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
     }
     // input rows are addressed relative to row m_begin - 64, which sits at physical row 0
     bf16* abase = const_cast<bf16*>(p.A) + (static_cast<ptrdiff_t>(m_begin) - 64) * p.cs;
-    auto issue_rows = [&](int rel0, int phys0) {  // 8 rows from relative row rel0 (a multiple of 8) to physical row phys0
+    // (returns the LDS byte of this lane's chunk, or -1 if the row is outside the tensor: what the transform needs later)
+    auto issue_rows = [&](int rel0, int phys0) -> int {  // 8 rows from relative row rel0 (a multiple of 8) to physical row phys0
         const int rel = rel0 + lrow;
         const int m = m_begin - 64 + rel;
         const bool ok = m >= 0 && m < p.M;
         const uint32_t voff = ok ? static_cast<uint32_t>(rel * p.cs + kchunk) * 2u : OUT_OF_RANGE;
         buffer_load_lds_16(abase, (lds_void_t*)(smem + phys0 * 128), voff, 0);
+        return ok ? phys0 * 128 + lane * 16 : -1;
     };
+    float xsc[8], xsh[8];  // XF: scale / shift of the 8 channels of this lane's chunk (the same logical chunk in every piece)
+    if constexpr (XF) {
+        *reinterpret_cast<f32x4*>(xsc) = *reinterpret_cast<const f32x4*>(p.xf + 2 * 64 + kchunk);
+        *reinterpret_cast<f32x4*>(xsc + 4) = *reinterpret_cast<const f32x4*>(p.xf + 2 * 64 + kchunk + 4);
+        *reinterpret_cast<f32x4*>(xsh) = *reinterpret_cast<const f32x4*>(p.xf + 3 * 64 + kchunk);
+        *reinterpret_cast<f32x4*>(xsh + 4) = *reinterpret_cast<const f32x4*>(p.xf + 3 * 64 + kchunk + 4);
+    }
+    auto xform = [&](int at) {
+        if (at < 0) return;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + at);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * xsc[e] + xsh[e], 0.f));
+        *reinterpret_cast<bf16x8*>(smem + at) = v;
+    };
+    int pend_a[2] = {-1, -1}, pend_b = -1, pend_c = -1;  // XF: chunks requested and not yet transformed
     int ld_rel = 0, ld_phys = 0;  // the next row to fetch (relative / physical); both multiples of 8
-    auto refill = [&](int pieces_per_wave) {  // 8 waves x pieces x 8 rows
+    auto refill = [&](int pieces_per_wave, int* at) {  // 8 waves x pieces x 8 rows
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (k >= pieces_per_wave) continue;
             const int q = (wave + 8 * k) * 8;
             int ph = ld_phys + q;
             ph = ph >= HALO_CAP ? ph - HALO_CAP : ph;
-            issue_rows(ld_rel + q, ph);
+            at[k] = issue_rows(ld_rel + q, ph);
         }
         ld_rel += pieces_per_wave * 64;
         ld_phys += pieces_per_wave * 64;
         ld_phys = ld_phys >= HALO_CAP ? ld_phys - HALO_CAP : ld_phys;
     };
+    int first_at[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) issue_rows((wave + 8 * k) * 8, (wave + 8 * k) * 8);  // rows [m_begin - 64, m_begin + 320)
+    for (int k = 0; k < 6; ++k) first_at[k] = issue_rows((wave + 8 * k) * 8, (wave + 8 * k) * 8);  // rows [m_begin - 64, m_begin + 320)
     ld_rel = ld_phys = 384;
     if (tid < 32) *reinterpret_cast<uint32_t*>(smem + HALO_Z_OFF + 4 * tid) = 0u;
+    if constexpr (XF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xform(first_at[k]);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- fragment addressing
@@ -1409,7 +1439,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
     for (int ti = 0; ti < ntiles; ++ti) {
         const int m0 = m_begin + (ti << 8);
         const bool more = ti + 1 < ntiles;
-        if (more) refill(2);
+        if (more) refill(2, pend_a);
         // this lane's two fragment rows: which taps stay inside the image, and the row's place in the buffer
         bool hm[2], hp[2], wm_[2], wp[2];
         int rowp[2];
@@ -1477,8 +1507,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         // The last portion of the previous tile's refill (rows that the taps from number 5 on read) has landed: what this
         // wave has issued since are the previous tile's 4 stores and, if there is a next tile, this tile's first portion
         // (2 requests).  (Only the launch's very last tile can store fewer rows, and nothing is refilled after it.)
-        if (more) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // and nobody reads rows below m0 - 1 any more
-        else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (XF) {
+            __builtin_amdgcn_sched_barrier(0);
+            xform(pend_c);
+            pend_c = -1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // and nobody reads rows below m0 - 1 any more
         // BatchNorm-backward sums: this lane's pre-normalisation activations of the tile, requested six taps before
         // their use (rows beyond M read the last row)
         u32x4 yraw[2][2];
@@ -1492,7 +1528,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
                     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(yraw[i][ps]) : "v"(q) : "memory");
                 }
         }
-        if (more) refill(1);
+        if (more) refill(1, &pend_b);
         load(integral_constant<int, 4>{}, B0);
         mma(integral_constant<int, 3>{}, B1);
         load(integral_constant<int, 5>{}, B1);
@@ -1500,7 +1536,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         load(integral_constant<int, 6>{}, B0);
         mma(integral_constant<int, 5>{}, B1);
         asm volatile("s_barrier" ::: "memory");  // nobody reads rows below m0 + W - 1 any more
-        if (more) refill(1);
+        if (more) refill(1, &pend_c);
         load(integral_constant<int, 7>{}, B1);
         mma(integral_constant<int, 6>{}, B0);
         load(integral_constant<int, 8>{}, B0);
@@ -1512,6 +1548,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         if (more) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (XF) {
+            if (more) {
+                xform(pend_a[0]);
+                xform(pend_a[1]);
+                xform(pend_b);
+            }
+        }
 
         // ---- epilogue: 16 rows at a time -> bf16 -> wave-private LDS rows -> 16-byte row segments (staging layout as in
         // gather_gemm_ring_kernel)
@@ -1570,7 +1613,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         }
         base_phys += 256;
         base_phys = base_phys >= HALO_CAP ? base_phys - HALO_CAP : base_phys;
-        asm volatile("s_barrier" ::: "memory");  // every wave is done with this tile's rows, and everybody's refill has landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with this tile's rows, and everybody's refill has landed
     }
 
     // ---- the workgroup's sums -> one of the launch's accumulator slots
@@ -1614,7 +1657,7 @@ static bool conv3x3_halo_applies(const GatherGemmArgs& a) {
     if (!enabled || a.tw != 0 || a.T != 9 || a.C != 64 || a.N != 64 || a.cs != 64 || a.ldo != 64) return false;
     if (a.istr != 1 || a.ostr != 1 || a.oph != 0 || a.opw != 0) return false;
     if (a.OA != a.Hin || a.OB != a.Win || a.Hout != a.Hin || a.Wout != a.Win || a.Win < 24 || a.Win > 63) return false;
-    if (a.bias != nullptr || a.addend != nullptr || a.act != 0 || a.xf != nullptr || a.out_nt > 1) return false;
+    if (a.bias != nullptr || a.addend != nullptr || a.act != 0 || a.out_nt > 1 || (a.xf != nullptr && a.bn_y != nullptr)) return false;
     if (a.bn_y != nullptr && (a.bn_bits != nullptr || a.bn_y2 != nullptr || a.stats == nullptr || a.bn_consts == nullptr || a.stat_rows != 3))
         return false;
     unsigned seen = 0;
@@ -1633,9 +1676,9 @@ static int launch_conv3x3_halo(const GatherGemmArgs& a, hipStream_t stream) {
     const int grid = pdt_cdiv(total, per);
     // 32-bit byte offsets from the workgroup's first row
     if ((static_cast<long long>(per) * 256 + 1024) * 128 >= (1ll << 31)) return -1;
-    auto kernel = a.bn_y != nullptr ? conv3x3_halo_kernel<4> : conv3x3_halo_kernel<0>;
-    static bool configured[2] = {false, false};
-    const int which = a.bn_y != nullptr ? 1 : 0;
+    auto kernel = a.bn_y != nullptr ? conv3x3_halo_kernel<4> : (a.xf != nullptr ? conv3x3_halo_kernel<0, true> : conv3x3_halo_kernel<0>);
+    static bool configured[3] = {false, false, false};
+    const int which = a.bn_y != nullptr ? 1 : (a.xf != nullptr ? 2 : 0);
     if (!configured[which]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
         if (e != hipSuccess) return static_cast<int>(e);
@@ -1898,7 +1941,8 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
                             const int* tap_woff, int tile, int smallc, const void* zeros, const void* bn_y,
                             const float* bn_consts, const void* bn_bits, const void* bn_y2, const float* bn_consts2,
                             int act, void* out2, const void* act_src, const float* xf, const float* pivot, void* stream) {
-    if (xf != nullptr && (smallc || tile != 16)) return -1;  // the operand transform lives in the 256x256 two-stage kernel
+    // the operand transform lives in the 256x256 two-stage kernel and in the shared-rows 3x3 kernel (tiles 14 / 15, checked below)
+    if (xf != nullptr && (smallc || (tile != 16 && tile != 14 && tile != 15))) return -1;
     if (act < 0 || act > 2 || (act == 1 && (out2 == nullptr || bias == nullptr)) || (act == 2 && act_src == nullptr)) return -1;
     if (M <= 0 || N <= 0 || T < 0 || T > GG_MAX_TAPS || C <= 0) return -1;
     if (!smallc && (C % GG_BK) != 0) return -1;
@@ -1961,6 +2005,7 @@ PDT_API int pdt_gather_gemm(const void* A, const void* B, void* Out, float* stat
         return N <= 64 ? launch_gather_gemm<128, 64, 4, 1, true>(a, s) : launch_gather_gemm<128, 128, 2, 2, true>(a, s);
     }
     if ((tile == 14 || tile == 15) && conv3x3_halo_applies(a)) return launch_conv3x3_halo(a, s);
+    if (xf != nullptr && tile != 16) return -1;
     switch (tile) {
         case 0: return launch_gather_gemm<128, 128, 2, 2>(a, s);
         case 1: return launch_gather_gemm<128, 64, 4, 1>(a, s);
@@ -2730,7 +2775,10 @@ struct WgradHalo {
     static constexpr int REQ = 4 + YP;                  // DMA requests per wave and K-step
 };
 
-template <int C>
+// XF: the X operand is relu(X * scale[c] + shift[c]) (see conv3x3_halo_kernel): a lane rewrites the chunks its own requests
+// fetched - both copies of a mirrored block - after the counted wait that retires them and in front of the K-step's
+// barrier; border positions and rows outside the tensor stay zero.
+template <int C, bool XF = false>
 __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, const int P) {
     using G = WgradHalo<C>;
     constexpr int BR = G::BR, KS = G::KS, KK = G::KK, RB = G::RB, NJ = G::NJ, GJ = G::GJ, NG = G::NG;
@@ -2780,6 +2828,30 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
         buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
         buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 3 ? 8 * 8192 : 0)), voff, 0);
     };
+    float xsc[8], xsh[8];  // XF: scale / shift of the 8 channels of this lane's chunk (the same logical chunk in every block)
+    if constexpr (XF) {
+        constexpr int CPR = RB / 16, RPP = 1024 / RB;
+        const int lrow = lane / CPR, pc = lane % CPR;
+        const int q = RPP * wave + lrow;  // (block starts are multiples of 8 rows: the swizzle sees only these bits)
+        const int sw = C == 64 ? ((q >> 1) & 3) : (q & 7);
+        const int c0 = ((((pc >> 1) ^ sw) << 1) | (pc & 1)) * 8;
+        *reinterpret_cast<f32x4*>(xsc) = *reinterpret_cast<const f32x4*>(p.xf + 2 * C + c0);
+        *reinterpret_cast<f32x4*>(xsc + 4) = *reinterpret_cast<const f32x4*>(p.xf + 2 * C + c0 + 4);
+        *reinterpret_cast<f32x4*>(xsh) = *reinterpret_cast<const f32x4*>(p.xf + 3 * C + c0);
+        *reinterpret_cast<f32x4*>(xsh + 4) = *reinterpret_cast<const f32x4*>(p.xf + 3 * C + c0 + 4);
+    }
+    auto xform_x = [&](int b) {  // this lane's chunk of X block b, where it landed (and its mirror)
+        constexpr int CPR = RB / 16, RPP = 1024 / RB;
+        const int pos = (blk0 + b - 1) & 7;
+        const int q = ps + BR * (b - 1) + RPP * wave + lane / CPR;
+        if (pixel_of(q) < 0) return;
+        char* at = smem + pos * 8192 + wave * 1024 + lane * 16;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(at);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * xsc[e] + xsh[e], 0.f));
+        *reinterpret_cast<bf16x8*>(at) = v;
+        if (pos < 3) *reinterpret_cast<bf16x8*>(at + 8 * 8192) = v;
+    };
     auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + KS ks, + KS), 64 of the channels; rows beyond the split are zeros
         const int lrow = lane >> 3, pc = lane & 7;
 #pragma unroll
@@ -2795,7 +2867,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     // wave and K-step (two X blocks twice, the dY pieces), so "all but the last REQ" is what a K-step waits for.
     issue_x(0); issue_x(1); issue_x(2); issue_x(3); issue_x(4); issue_x(5);
     issue_y(0); issue_y(1);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (XF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        for (int b2 = 0; b2 < 6; ++b2) xform_x(b2);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     f32x4 acc[2][NJ];
 #pragma unroll
@@ -2823,7 +2900,17 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     }
 
     for (int ks = 0; ks < nsteps; ++ks) {
-        if (ks > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G::REQ) : "memory");
+        if (ks > 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::REQ) : "memory");
+            if constexpr (XF) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks >= 2) {  // the blocks requested two K-steps ago have landed (blocks 0-5 were done in front of the loop)
+                    xform_x(2 * ks + 2);
+                    xform_x(2 * ks + 3);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         issue_x(2 * ks + 6);
         issue_x(2 * ks + 7);
         issue_y(ks + 2);
@@ -3097,12 +3184,14 @@ static int launch_wgrad3x3_halo_c(WgradArgs a, int splits, hipStream_t stream) {
     a.m_per_split = kps;
     a.div_ab = make_fastdiv(HpWp);
     a.div_b = make_fastdiv(Wp);
-    auto kernel = wgrad3x3_halo_kernel<C>;
-    static bool configured = false;
-    if (!configured) {
+    if (a.xf != nullptr && C != 64) return -1;  // (the 128-channel flavour has no registers left for the transform)
+    auto kernel = (C == 64 && a.xf != nullptr) ? wgrad3x3_halo_kernel<C, C == 64> : wgrad3x3_halo_kernel<C, false>;
+    static bool configured[2] = {false, false};
+    bool& conf = configured[a.xf != nullptr ? 1 : 0];
+    if (!conf) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) return static_cast<int>(e);
-        configured = true;
+        conf = true;
     }
     hipLaunchKernelGGL(kernel, dim3(grid, C / 64), dim3(512), G::LDS, stream, a, static_cast<int>(P));
     return pdt_launch_status();
@@ -3110,7 +3199,7 @@ static int launch_wgrad3x3_halo_c(WgradArgs a, int splits, hipStream_t stream) {
 
 static int launch_wgrad3x3_halo(const WgradArgs& a, int splits, hipStream_t stream) {
     if (a.T != 9 || (a.C != 64 && a.C != 128) || a.N != a.C || a.istr != 1 || a.OA != a.Hin || a.OB != a.Win || a.Win < 1 || a.tw != 0 ||
-        a.xf != nullptr || a.dbias != nullptr || (a.M % (a.Hin * a.Win)) != 0)
+        a.dbias != nullptr || (a.M % (a.Hin * a.Win)) != 0)
         return -1;
     if (a.Win + 3 > WgradHalo<64>::BR && a.C == 64) return -1;   // the halo W + 3 fits one block
     if (a.Win + 3 > WgradHalo<128>::BR && a.C == 128) return -1;

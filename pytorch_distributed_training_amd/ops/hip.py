@@ -677,7 +677,7 @@ def _launch_wgrad(dy, x, dw, M, N, ldy, C, taps, ldw, Hin, Win, istr, OA, OB, sm
     if tile == 16 and WGRAD_PP and len(taps) == 1 and xf is None:
         tile = 17  # (the launcher falls back to 16 when the tap is not the identity mapping)
     if (WGRAD_HALO and tile >= 10 and not smallc and len(taps) == 9 and C in (64, 128) and N == C and istr == 1 and OA == Hin
-            and OB == Win and Win <= (61 if C == 64 else 29) and xf is None and dbias is None and M >= 64 * _num_cus()
+            and OB == Win and Win <= (61 if C == 64 else 29) and (xf is None or C == 64) and dbias is None and M >= 64 * _num_cus()
             and sorted((t[0], t[1]) for t in taps) == _TAPS_3X3):
         # 3x3 / stride 1 / 64 -> 64 (128 -> 128): all columns of 64 output channels in one workgroup, the input rows shared
         # between the taps
@@ -1196,6 +1196,12 @@ def bn_act(y, stats, bn, relu: bool = True):
 # the transform costs more than the saved pass - bench/bn_fuse_bench.py); 2: wherever the kernels allow (saves the
 # most memory).
 FUSE_BN_INTO_1X1 = int(_os.environ.get("PDT_FUSE_BN_1X1", "1"))
+# 1: BatchNorm + ReLU applied inside the 3x3 / 64 -> 64 consumer's shared-rows kernels instead of as a pass of its own.
+# Measured on ResNet-50 at batch 4000 (same box): the pass it removes is 1.6 ms per step, the transform costs the forward
+# kernel 0.45 ms and the weight-gradient kernel 0.75 ms (it sits between the wait that retires a block and the barrier
+# that publishes it), the step time is unchanged within 0.1 % and 4.5 GiB less memory is held - so it is off by default.
+FUSE_BN_INTO_3X3 = int(_os.environ.get("PDT_FUSE_BN_3X3", "0"))
+_CONV3X3_HALO = _os.environ.get("PDT_CONV3X3_HALO", "1") not in ("", "0")  # (the kernel library reads the same switch)
 
 
 def _can_fuse_bn_into_conv(y_prev, bn, weight, stride: int, padding: int) -> bool:
@@ -1206,6 +1212,13 @@ def _can_fuse_bn_into_conv(y_prev, bn, weight, stride: int, padding: int) -> boo
     if not FUSE_BN_INTO_1X1 or not WGRAD_RING or WGRAD_RING >= 10 or _TILE_WIDE >= 0:
         return False
     n, c, r, s = weight.shape
+    if (r, s) == (3, 3):
+        # 3x3 / stride 1 / 64 -> 64 on the kernels that keep one copy of the input rows in LDS: there the transform is
+        # applied once per input element (the tap-table kernels would repeat it for every tap)
+        nb, _, h, w = y_prev.shape
+        M = nb * h * w
+        return bool(FUSE_BN_INTO_3X3 and WGRAD_HALO and _CONV3X3_HALO and stride == 1 and padding == 1 and bn.training and c == 64
+                    and n == 64 and 24 <= w <= 61 and M >= 64 * _num_cus() and _pick_tile(M, n, 9) in (14, 15))
     if (r, s) != (1, 1) or stride != 1 or padding != 0 or not bn.training or c % 64 or n % 64 or c > 2048:
         return False
     if FUSE_BN_INTO_1X1 == 1 and c > 128:
@@ -1218,7 +1231,8 @@ def _can_fuse_bn_into_conv(y_prev, bn, weight, stride: int, padding: int) -> boo
 
 
 class _BnReluConv1x1(torch.autograd.Function):
-    """conv1x1(relu(bn(y_prev))) without ever writing relu(bn(y_prev)): the forward GEMM and the weight-gradient
+    """conv(relu(bn(y_prev))) for a 1x1 - or, on the shared-rows kernels, a 3x3 / 64 -> 64 - convolution of stride 1
+    without ever writing relu(bn(y_prev)): the forward GEMM and the weight-gradient
     kernel normalise their operand tiles in LDS, the data-gradient kernel takes BatchNorm's backward sums in its
     epilogue (mask recomputed from y_prev), and BatchNorm's backward apply pass produces the gradient of y_prev."""
 
@@ -1232,8 +1246,10 @@ class _BnReluConv1x1(torch.autograd.Function):
         y = _empty_nhwc(nb, n, h, w_, y_prev.device)
         _check_size(y)
         stats = ARENA.alloc((STAT_SLOTS + 1, 2, n), y_prev.device)
-        one = [(0, 0, 0)]
-        _launch_gather_gemm(y_prev, SHADOWS.fwd(weight), y, stats, None, M, n, c, n, c, one, h, w_, 1, h, w_, h, w_, 1, 0, 0,
+        r = weight.shape[2]  # 1 (no padding) or 3 (padding 1)
+        pad = r // 2
+        taps = [(i - pad, j - pad, (i * r + j) * c) for i in range(r) for j in range(r)]
+        _launch_gather_gemm(y_prev, SHADOWS.fwd(weight), y, stats, None, M, n, r * r * c, n, c, taps, h, w_, 1, h, w_, h, w_, 1, 0, 0,
                             xf=consts, pivot=_stat_pivot(weight))
         ctx.save_for_backward(y_prev, consts, weight, gamma, beta)
         ctx.geom = (nb, c, h, w_, n)
@@ -1249,23 +1265,28 @@ class _BnReluConv1x1(torch.autograd.Function):
             return None, None, None, None, None, None
         dy = _as_nhwc(dy)
         count = M = nb * h * w_
-        one = [(0, 0, 0)]
+        r = weight.shape[2]
+        pad = r // 2
         dw = None
         if ctx.needs_input_grad[5]:
-            sink = _grad_sink(weight, (n, 1, 1, c))
-            dwp = sink if sink is not None else torch.zeros((n, 1, 1, c), dtype=torch.float32, device=dy.device)
-            _launch_wgrad(dy, y_prev, dwp, M, n, n, c, one, c, h, w_, 1, h, w_, xf=consts)
+            sink = _grad_sink(weight, (n, r, r, c))
+            dwp = sink if sink is not None else torch.zeros((n, r, r, c), dtype=torch.float32, device=dy.device)
+            taps = [(i - pad, j - pad, (i * r + j) * c) for i in range(r) for j in range(r)]
+            _launch_wgrad(dy, y_prev, dwp, M, n, n, c, taps, r * r * c, h, w_, 1, h, w_, xf=consts)
             if sink is None:
                 dw = dwp.permute(0, 3, 1, 2)
         dyp = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
-            wt, npad = SHADOWS.dgrad(weight, 1)
+            wt, npad = SHADOWS.dgrad(weight, r * r)
+            if npad != n:
+                raise NotImplementedError("data gradient needs Cout % 64 == 0")
             da = _empty_nhwc(nb, c, h, w_, dy.device)
             slots = bn_stat = None
             if _dgrad_can_fuse_stats([(M, c)]):
                 slots = ARENA.alloc((STAT_SLOTS, 3, c), dy.device)
                 bn_stat = (y_prev, consts, None)
-            _launch_gather_gemm(dy, wt, da, slots, None, M, c, npad, c, n, one, h, w_, 1, h, w_, h, w_, 1, 0, 0, bn_stat=bn_stat)
+            dtaps = [(pad - i, pad - j, (i * r + j) * npad) for i in range(r) for j in range(r)]
+            _launch_gather_gemm(dy, wt, da, slots, None, M, c, r * r * npad, c, n, dtaps, h, w_, 1, h, w_, h, w_, 1, 0, 0, bn_stat=bn_stat)
             dyp, dgamma, dbeta, _ = _bn_backward(da, None, y_prev, consts, gamma, beta, count, c, mask_mode=2, slots=slots)
         return dyp, None, dgamma, dbeta, None, dw
 

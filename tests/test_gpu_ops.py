@@ -856,6 +856,58 @@ def test_block_tail_bn_sums_come_from_the_next_blocks_first_dgrad(hip, monkeypat
     assert seen[3][3] == (blocks == "projected+identity")
 
 
+@pytest.mark.parametrize("nb,hw,fusable", [(70, 56, True), (240, 29, True), (56, 61, True), (400, 23, False), (4, 56, False)])
+def test_bn_relu_fused_into_the_shared_rows_3x3_kernels(hip, monkeypatch, nb, hw, fusable):
+    """conv3x3(relu(bn(y))), 64 -> 64 channels: the kernels that keep one copy of the input rows in LDS apply the
+    normalisation to that copy (forward and weight gradient), so the normalised activation is never written.  Output,
+    statistics and all gradients against the path that materialises relu(bn(y)), and against fp32 PyTorch.  Images too
+    narrow for the kernel, or too few rows, take the materialising path."""
+    torch.manual_seed(6)
+    dev = _dev()
+    cin = cout = 64
+    y = hip.to_device_layout(torch.randn(nb, cin, hw, hw, device=dev) * 1.5 + 0.2)
+    w = nn.Parameter((torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)).contiguous(memory_format=torch.channels_last))
+    gamma, beta = torch.empty(cin, device=dev).uniform_(0.5, 1.5), torch.empty(cin, device=dev).uniform_(-0.5, 0.5)
+    yf = y.float()
+    st = torch.zeros(hip.STAT_SLOTS + 1, 2, cin, device=dev)
+    st[0, 0] = yf.sum(dim=(0, 2, 3))
+    st[0, 1] = (yf * yf).sum(dim=(0, 2, 3))
+    g = torch.randn(nb, cout, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    launched = []
+    real_launch = hip._launch_gather_gemm
+    monkeypatch.setattr(hip, "_launch_gather_gemm", lambda *a, **kw: (launched.append(kw.get("xf") is not None), real_launch(*a, **kw))[1])
+    for fused in (True, False):
+        monkeypatch.setattr(hip, "FUSE_BN_INTO_3X3", 1 if fused else 0)
+        bn = nn.BatchNorm2d(cin).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(gamma)
+            bn.bias.copy_(beta)
+        for p in list(bn.parameters()) + [w]:
+            p.grad = None
+        yy = y.clone().requires_grad_(True)
+        launched.clear()
+        out, stats = hip.bn_relu_conv2d(yy, st.clone(), bn, w, 1, 1)
+        assert any(launched) == (fused and fusable), "the operand transform was (not) used"
+        out.backward(g)
+        torch.cuda.synchronize()
+        res[fused] = (out.float().clone(), stats[:-1].sum(0).clone(), yy.grad.float().clone(), bn.weight.grad.clone(),
+                      bn.bias.grad.clone(), w.grad.clone())
+    for name, a, b in zip(("out", "stats", "dy", "dgamma", "dbeta", "dw"), res[True], res[False]):
+        assert _rel_err(a, b) < 4e-3, name
+    yr = yf.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    wr = _bf16_round(w.detach()).requires_grad_(True)
+    a = F.relu(F.batch_norm(yr, None, None, gr, br, training=True, eps=1e-5))
+    o = F.conv2d(a, wr, padding=1)
+    o.backward(g.float())
+    out, _, dy, dgamma, dbeta, dw = res[True]
+    assert _rel_err(out, o) < 1e-2
+    assert _rel_err(dy, yr.grad) < 2e-2
+    assert _rel_err(dgamma, gr.grad) < 2e-2 and _rel_err(dbeta, br.grad) < 2e-2
+    assert _rel_err(dw, wr.grad) < 1e-2
+
+
 def test_transposed_weight_copies_are_rebuilt_in_one_launch_after_the_optimizer_step(hip):
     """The data-gradient kernels read [Cin][taps][Cout] bf16 copies of the weights; once they exist, the optimizer step
     refreshes all of them with one batched launch, so the next backward pass finds them current."""
