@@ -19,6 +19,7 @@ S="--dataset synthetic --no-progress"
 run r18_default        $S --dataset-length 4096
 run r18_dp_host        $S --distributed --dataset-length 4096 --eval
 run r18_dp_graph       $S --distributed --dataset-length 4096 --hip-graph
+run r50_graph_224      $S --model resnet50 --image-size 224 --batch-size 64 --dataset-length 1920 --device-data --optimizer sgd --hip-graph
 run r50_dp_host        $S --distributed --model resnet50 --image-size 224 --batch-size 256 --dataset-length 5120 --num-workers 4 --optimizer sgd --learning-rate 0.05
 run r50_dp_accum_bf16  $S --distributed --model resnet50 --image-size 224 --batch-size 128 --dataset-length 2560 --num-workers 4 --optimizer sgd --grad-accum 2 --grad-dtype bf16
 run r50_dp_rsag_ckpt   $S --distributed --model resnet50 --image-size 224 --batch-size 128 --dataset-length 2560 --num-workers 4 --optimizer sgd --reduce-algorithm rs_ag --checkpoint-path "${TMPDIR:-/tmp}/pdt_matrix_r50.pt" --save-every 5
