@@ -2911,9 +2911,6 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        issue_x(2 * ks + 6);
-        issue_x(2 * ks + 7);
-        issue_y(ks + 2);
         const uint32_t xs = static_cast<uint32_t>(((blk0 + 2 * ks - 1) & 7) * 8192);  // the window's first row (block 2 ks)
         const uint32_t ys = static_cast<uint32_t>((ks & 3) * G::Y_STAGE);
         s16x4 ylo[KK][2], yhi[KK][2], xlo[3][GJ][KK], xhi[3][GJ][KK];  // dY: [slice][channel block]; X: [buffer][block in group][slice]
@@ -2967,6 +2964,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
             __builtin_amdgcn_sched_barrier(0);
             mma(gr, gr % 3);
             __builtin_amdgcn_sched_barrier(0);
+            if (gr == 0) {
+                // This K-step's requests (for two K-steps ahead), behind the first MFMAs rather than right after the
+                // barrier: their address arithmetic (a row's real pixel, four times) then runs under the matrix pipe
+                // instead of in front of the K-step's first fragment read.
+                issue_x(2 * ks + 6);
+                issue_x(2 * ks + 7);
+                issue_y(ks + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loader's trailing requests
@@ -3074,8 +3080,6 @@ __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, con
     for (int ks = 0; ks < nsteps; ++ks) {
         // per K-step and wave: X, X', Y, Y' - the dY rows of this step were the last two requests of step ks - 3
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        issue_x(ks0 + ks + WR_LAX);
-        issue_y(ks + 3);
         const long long rb = in_row(ks0 + ks) * RB - org;  // position 0 of the output row in kernel row 0
         const uint32_t ys = static_cast<uint32_t>((ks & 3) * 16384);
         s16x4 ylo[4], yhi[4], xlo[7][4], xhi[7][4];  // [..][32-position slice]
@@ -3122,6 +3126,11 @@ __global__ __launch_bounds__(512) void wgrad_rows7_kernel(const WgradArgs p, con
             __builtin_amdgcn_sched_barrier(0);
             mma(kh);
             __builtin_amdgcn_sched_barrier(0);
+            if (kh == 0) {  // this K-step's requests, behind the first MFMAs (their address arithmetic runs under the matrix pipe)
+                issue_x(ks0 + ks + WR_LAX);
+                issue_y(ks + 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
