@@ -1439,7 +1439,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
     for (int ti = 0; ti < ntiles; ++ti) {
         const int m0 = m_begin + (ti << 8);
         const bool more = ti + 1 < ntiles;
-        if (more) refill(2, pend_a);
         // this lane's two fragment rows: which taps stay inside the image, and the row's place in the buffer
         bool hm[2], hp[2], wm_[2], wp[2];
         int rowp[2];
@@ -1500,6 +1499,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         load(integral_constant<int, 0>{}, B0);
         load(integral_constant<int, 1>{}, B1);
         mma(integral_constant<int, 0>{}, B0);
+        if (more) refill(2, pend_a);  // (behind the first MFMAs; nobody reads the rows it overwrites since the tile began)
         load(integral_constant<int, 2>{}, B0);
         mma(integral_constant<int, 1>{}, B1);
         load(integral_constant<int, 3>{}, B1);
@@ -1781,7 +1781,6 @@ __global__ __launch_bounds__(512) void conv_rows7_kernel(const GatherGemmArgs p,
 
     for (int ti = 0; ti < ntiles; ++ti) {
         const int m0 = m_begin + (ti << 8);
-        issue_tile(ti + ROWS_LA);
         uint32_t a_byte[2];  // LDS-relative byte of this lane's chunk of kernel row 0, per 16-pixel block (before the wrap)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1810,6 +1809,10 @@ __global__ __launch_bounds__(512) void conv_rows7_kernel(const GatherGemmArgs p,
         for (int kh = 0; kh < T; ++kh) {
             if (kh + 1 < T) load(kh + 1, (kh + 1) & 1);
             mma(kh, kh & 1);
+            if (kh == 0) {  // this tile's requests, behind its first MFMAs (their address arithmetic runs under the matrix pipe)
+                issue_tile(ti + ROWS_LA);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // the previous tile's requests have landed (this tile's may stay in flight); in front of the stores
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROWS_REQ) : "memory");
