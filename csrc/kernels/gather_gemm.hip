@@ -2055,6 +2055,10 @@ struct WgradArgs {
     int tap_woff[GG_MAX_TAPS];
 };
 
+// ring weight-gradient kernels with at least this many stages request the next stage behind the K-step's first MFMAs
+#ifndef PDT_WGRAD_ISSUE_MID_MIN_STAGES
+#define PDT_WGRAD_ISSUE_MID_MIN_STAGES 2
+#endif
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
 __device__ __forceinline__ bf16x8 lds_read_tr8(const bf16* base_lo, const bf16* base_hi) {
@@ -2464,6 +2468,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
     // A K-step is worked off in units of (32-pixel slice kk, group of dY fragments): the fragment reads of the next unit
     // are issued before the MFMAs of the current one and awaited with a counted lgkmcnt, so within a wave the LDS
     // latency hides behind 16 MFMAs instead of being paid at the head of every slice.
+    constexpr bool WGRAD_ISSUE_MID = NS >= PDT_WGRAD_ISSUE_MID_MIN_STAGES;
     auto compute = [&](int slot, const bool bias_step) {
         constexpr int HG = FN >= 4 ? 2 : 1;  // groups of dY fragments per slice
         constexpr int GI = FN / HG;
@@ -2527,6 +2532,13 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
             __builtin_amdgcn_sched_barrier(0);
         };
         unit(std::integral_constant<int, 0>{});
+        if constexpr (!PLAIN && WGRAD_ISSUE_MID) {
+            // Gather loader: the next stage is requested here, behind the K-step's first MFMAs, instead of right after the
+            // barrier - its index arithmetic (two divisions per piece) then runs under the matrix pipe and not in front
+            // of the K-step's first fragment reads.
+            if (ld_issued < nsteps) issue_stage();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         unit(std::integral_constant<int, 1>{});
         if constexpr (UNITS == 4) {
             unit(std::integral_constant<int, 2>{});
@@ -2648,7 +2660,9 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, int block, i
         } else {
             if (ld_issued - (s + 1) >= NS - 2) wait_vm_and_barrier<(NS - 2) * LPW>();
             else wait_vm_and_barrier<0>();
-            if (ld_issued < nsteps) issue_stage();
+            if constexpr (!WGRAD_ISSUE_MID) {
+                if (ld_issued < nsteps) issue_stage();
+            }
         }
         const bool bias_step = bias_turn == 0;
         compute(slot, bias_step);
