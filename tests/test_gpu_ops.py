@@ -111,6 +111,36 @@ def test_conv_narrow_tile_variants(hip, monkeypatch, tile):
         test_conv_forward_backward(hip, 40, 3, 64, 7, 2, 3, 224)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 64, 3, 1, 1, 40, 56), (64, 64, 3, 1, 1, 57, 31), (128, 128, 3, 1, 1, 19, 28),
+                                                       (3, 64, 7, 2, 3, 160, 224), (3, 64, 7, 2, 3, 224, 150)])
+def test_shared_rows_kernels_on_images_that_are_not_square(hip, monkeypatch, cin, cout, k, stride, pad, h, w):
+    """The kernels that keep one copy of the input rows in LDS decode a row index into (image, row, column) themselves
+    (forward: which taps leave the image, or where a pixel's kernel rows start; weight gradient: the padded pixel
+    numbering): heights and widths that differ."""
+    monkeypatch.setattr(hip, "_TILE_NARROW", 15)
+    torch.manual_seed(3)
+    dev = _dev()
+    nb = 37 if cin >= 64 else 9
+    x = torch.randn(nb, cin, h, w, device=dev)
+    wt = nn.Parameter((torch.randn(cout, cin, k, k, device=dev) / math.sqrt(cin * k * k)).contiguous(memory_format=torch.channels_last))
+    xb = hip.to_device_layout(x).requires_grad_(cin % 64 == 0)
+    y, stats = hip.conv2d_stats(xb, wt, stride, pad)
+    xr = _bf16_round(x).requires_grad_(True)
+    wr = _bf16_round(wt.detach()).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    assert y.shape == yr.shape
+    assert _rel_err(y, yr) < 6e-3
+    yf = y.float()
+    ssum = stats[:-1].sum(dim=0)
+    assert torch.allclose(ssum[0], yf.sum(dim=(0, 2, 3)), rtol=2e-3, atol=2e-2 * math.sqrt(yf[:, 0].numel()))
+    g = torch.randn_like(yr)
+    y.backward(g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    yr.backward(_bf16_round(g))
+    assert _rel_err(wt.grad, wr.grad) < 8e-3
+    if cin % 64 == 0:
+        assert _rel_err(xb.grad, xr.grad) < 8e-3
+
+
 @pytest.mark.parametrize("nb,hw", [(24, 28), (40, 17), (23, 29)])
 def test_wgrad_of_the_128_channel_3x3_layers_with_shared_input_rows(hip, monkeypatch, nb, hw):
     """128 -> 128 channels, 3x3, stride 1: the weight-gradient kernel that reduces over padded pixel indices and serves all
