@@ -1385,6 +1385,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * xsc[e] + xsh[e], 0.f));
         *reinterpret_cast<bf16x8*>(smem + at) = v;
     };
+    auto xform3 = [&](int a0, int a1, int a2) {  // three chunks: all reads first, so that the LDS round trips overlap
+        const int at[3] = {a0, a1, a2};
+        bf16x8 v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (at[k] >= 0) v[k] = *reinterpret_cast<const bf16x8*>(smem + at[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (at[k] < 0) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = f32_to_bf16(fmaxf(bf16_to_f32(v[k][e]) * xsc[e] + xsh[e], 0.f));
+            *reinterpret_cast<bf16x8*>(smem + at[k]) = v[k];
+        }
+    };
     int pend_a[2] = {-1, -1}, pend_b = -1, pend_c = -1;  // XF: chunks requested and not yet transformed
     int ld_rel = 0, ld_phys = 0;  // the next row to fetch (relative / physical); both multiples of 8
     auto refill = [&](int pieces_per_wave, int* at) {  // 8 waves x pieces x 8 rows
@@ -1549,11 +1563,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const GatherGemmArgs 
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (XF) {
-            if (more) {
-                xform(pend_a[0]);
-                xform(pend_a[1]);
-                xform(pend_b);
-            }
+            if (more) xform3(pend_a[0], pend_a[1], pend_b);
         }
 
         // ---- epilogue: 16 rows at a time -> bf16 -> wave-private LDS rows -> 16-byte row segments (staging layout as in
@@ -2832,6 +2842,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     // positions 0-2 exist a second time behind position 7.  Every block is requested twice - the second request goes to
     // the mirror position if there is one and to the same place otherwise - so that a K-step always issues the same
     // number of requests (the counted waits below rely on that).
+    uint32_t x_real = 0;  // XF: bit b & 31 = this lane's row of block b is a real pixel (blocks are transformed at most 6 behind their request)
     auto issue_x = [&](int b) {
         constexpr int CPR = RB / 16, RPP = 1024 / RB;  // chunks per row, rows per piece
         const int lrow = lane / CPR, pc = lane % CPR;
@@ -2844,6 +2855,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
         char* dst = smem + pos * 8192 + wave * 1024;
         buffer_load_lds_16(xbase, (lds_void_t*)dst, voff, 0);
         buffer_load_lds_16(xbase, (lds_void_t*)(dst + (pos < 3 ? 8 * 8192 : 0)), voff, 0);
+        if constexpr (XF) x_real = (x_real & ~(1u << (b & 31))) | ((m >= 0 ? 1u : 0u) << (b & 31));  // remembered for the transform
     };
     float xsc[8], xsh[8];  // XF: scale / shift of the 8 channels of this lane's chunk (the same logical chunk in every block)
     if constexpr (XF) {
@@ -2857,17 +2869,28 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
         *reinterpret_cast<f32x4*>(xsh) = *reinterpret_cast<const f32x4*>(p.xf + 3 * C + c0);
         *reinterpret_cast<f32x4*>(xsh + 4) = *reinterpret_cast<const f32x4*>(p.xf + 3 * C + c0 + 4);
     }
-    auto xform_x = [&](int b) {  // this lane's chunk of X block b, where it landed (and its mirror)
-        constexpr int CPR = RB / 16, RPP = 1024 / RB;
-        const int pos = (blk0 + b - 1) & 7;
-        const int q = ps + BR * (b - 1) + RPP * wave + lane / CPR;
-        if (pixel_of(q) < 0) return;
-        char* at = smem + pos * 8192 + wave * 1024 + lane * 16;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(at);
+    // this lane's chunks of X blocks b and b + 1, where they landed (and their mirrors): both reads first, so that the two
+    // LDS round trips overlap
+    auto xform_x2 = [&](int b) {
+        char* at[2];
+        bool real[2], mir[2];
+        bf16x8 v[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(fmaxf(bf16_to_f32(v[e]) * xsc[e] + xsh[e], 0.f));
-        *reinterpret_cast<bf16x8*>(at) = v;
-        if (pos < 3) *reinterpret_cast<bf16x8*>(at + 8 * 8192) = v;
+        for (int k = 0; k < 2; ++k) {
+            const int pos = (blk0 + b + k - 1) & 7;
+            at[k] = smem + pos * 8192 + wave * 1024 + lane * 16;
+            mir[k] = pos < 3;
+            real[k] = ((x_real >> ((b + k) & 31)) & 1u) != 0;
+            if (real[k]) v[k] = *reinterpret_cast<const bf16x8*>(at[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!real[k]) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = f32_to_bf16(fmaxf(bf16_to_f32(v[k][e]) * xsc[e] + xsh[e], 0.f));
+            *reinterpret_cast<bf16x8*>(at[k]) = v[k];
+            if (mir[k]) *reinterpret_cast<bf16x8*>(at[k] + 8 * 8192) = v[k];
+        }
     };
     auto issue_y = [&](int ks) {  // dY stage of K-step ks: padded rows [ps + KS ks, + KS), 64 of the channels; rows beyond the split are zeros
         const int lrow = lane >> 3, pc = lane & 7;
@@ -2887,7 +2910,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
     if constexpr (XF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        for (int b2 = 0; b2 < 6; ++b2) xform_x(b2);
+        for (int b2 = 0; b2 < 6; b2 += 2) xform_x2(b2);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -2922,8 +2945,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_halo_kernel(const WgradArgs p, c
             if constexpr (XF) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks >= 2) {  // the blocks requested two K-steps ago have landed (blocks 0-5 were done in front of the loop)
-                    xform_x(2 * ks + 2);
-                    xform_x(2 * ks + 3);
+                    xform_x2(2 * ks + 2);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
